@@ -1,0 +1,196 @@
+/*
+ * slime_hip.h -- C ABI of libslime_hip.so: the MI355X (gfx950) native visual-encoding hot path of SliME.
+ *
+ * The reference (yfzhang114/SliME) has NO native layer: its hot path is Python calling
+ * transformers / torch.nn.  This header is therefore a NEW boundary; each entry
+ * point names the reference interface whose arithmetic it replaces (paths relative to the reference
+ * repo; "HF" = transformers/models/clip/modeling_clip.py, third-party, lines of v5.15.0).
+ *
+ * Conventions (all functions):
+ *   - extern "C", plain pointers + sizes, a hipStream_t passed as void*; no torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - return 0 on success, a negative SLIME_E* code otherwise; never throws; slime_last_error()
+ *     returns a thread-local message for the last failure;
+ *   - no hidden allocation: scratch comes from the caller (`ws`, sized by the matching
+ *     *_workspace_bytes query, 256-byte aligned); no global mutable state; calls on distinct
+ *     streams with distinct workspaces may run concurrently;
+ *   - "T" is the 16-bit MFMA operand type selected by `dtype` (SLIME_BF16 or SLIME_F16); all
+ *     accumulation, residual stream, LayerNorm and softmax statistics are fp32.
+ */
+#ifndef SLIME_HIP_H
+#define SLIME_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLIME_ABI_VERSION 1
+
+enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
+
+enum {
+    SLIME_OK = 0,
+    SLIME_EINVAL = -1,      /* bad argument / unsupported shape */
+    SLIME_EWORKSPACE = -2,  /* workspace too small or misaligned */
+    SLIME_ELAUNCH = -3      /* HIP launch error */
+};
+
+/* GEMM epilogues:  C = epi(A[M,K] * B[N,K]^T + bias[N]) */
+enum {
+    SLIME_EPI_BIAS_T = 0,        /* -> T                                   (q/k/v projections)          */
+    SLIME_EPI_BIAS_QUICKGELU_T,  /* x*sigmoid(1.702x) -> T                  (CLIP fc1, HF :346-350)      */
+    SLIME_EPI_BIAS_GELU_T,       /* exact erf GELU -> T                     (projector/builder.py:53-57) */
+    SLIME_EPI_BIAS_F32,          /* -> fp32                                                              */
+    SLIME_EPI_BIAS_RESID_F32     /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
+};
+
+int slime_abi_version(void);
+const char* slime_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Primitive operators (each is one kernel launch; exported so parity tests can pin every kernel)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* MFMA GEMM with fused epilogue.  A: T [M, lda>=K] row-major; B: T [N, K] row-major (nn.Linear
+ * weight layout); bias: fp32 [N] or NULL; C: T or fp32 [M, ldc].  Requires K % 64 == 0, N % 128 == 0.
+ * Replaces torch.nn.functional.linear / F.conv2d-as-GEMM on the path (HF :148-154,309-311,333,346-350). */
+int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
+               int M, int N, int K, int dtype, int epilogue, void* stream);
+
+/* Row-wise LayerNorm over fp32 rows (statistics in fp32, two-pass variance).
+ *   y = (x - mean) * rstd * w + b            (normalize != 0)    or   y = x   (normalize == 0)
+ *   out_f32[r]  = y                            if out_f32
+ *   out_t[r]    = T(y)                         if out_t
+ *   out_t2[r]   = T(y + add[r % add_period])   if out_t2   (key position term, sampler.py:164)
+ * D must be 128, 256 or 1024.  Replaces nn.LayerNorm (HF :370,379; sampler.py:106,158,168). */
+int slime_layernorm(const float* x, int ldx, int rows, int D, const float* w, const float* b, float eps,
+                    int normalize, float* out_f32, void* out_t, void* out_t2, const float* add,
+                    int add_period, int dtype, void* stream);
+
+/* im2col for the patch-embed conv: pixels [n,3,image,image] (pix_dtype BF16/F16/F32), rounded to T
+ * first as `images.to(dtype=self.dtype)` does (clip_encoder.py:55), -> T [n*g*g, kpad], column order
+ * (c, ky, kx) as Conv2d weight.flatten(1) (HF :148-154,209-210); columns >= 3*p*p are zero. */
+int slime_im2col(const void* pixels, int pix_dtype, void* out, int n, int image, int patch, int kpad,
+                 int dtype, void* stream);
+
+/* h[n, 1+P, D] = pre_layrnorm( cat(class_embedding, patch_out[n, P, D]) + position_embedding )
+ * (HF CLIPVisionEmbeddings.forward :212-217 + pre_layrnorm :642).  fp32 in/out. */
+int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
+                        const float* ln_b, float eps, float* h, int n, int P, int D, void* stream);
+
+/* Fused multi-head attention, softmax(Q K^T) V with fp32 online softmax; Q is expected PRE-SCALED
+ * by head_dim^-0.5 (folded into the q projection weights; exact, the scale is a power of two).
+ *   q: T, element (b, i, h, d) at q[b*q_bs + i*q_rs + h*head_dim + d]   (q_bs may be 0: shared queries)
+ *   k, v likewise with (k_bs,k_rs), (v_bs,v_rs);  o: T at o[b*o_bs + i*o_rs + h*head_dim + d].
+ * head_dim 64 (CLIP self-attention, HF :259-277) or 128 (Resampler nn.MultiheadAttention,
+ * sampler.py:128,162-165). */
+int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
+                    const void* v, long v_bs, long v_rs, void* o, long o_bs, long o_rs,
+                    int batch, int heads, int head_dim, int n_q, int n_kv, int dtype, void* stream);
+
+/* out[r, :] = g0*e0[r, :] + g1*e1[r, :],  (g0,g1) = softmax(x[r,:] @ w_gate) / (sum + 1e-6)
+ * (GatedBlock.noisy_top_k_gating eval path + mix, projector/builder.py:148,158-165,203-206). */
+int slime_gate_mix(const float* x, int D, const float* w_gate /* [D,2] */, const float* e0,
+                   const float* e1, float* out, int rows, int H, void* stream);
+
+/* Row gather + cast: out[(g*rows_out + r), :] = cast(in[(g*rows_in + row_off + r), :]),
+ * g < groups, r < rows_out.  in fp32, out dtype BF16/F16/F32.  (feature_select's [:,1:],
+ * clip_encoder.py:38-39, and output-dtype casts :52,56.) */
+int slime_gather_rows(const float* in, int rows_in, int row_off, void* out, int out_dtype,
+                      int groups, int rows_out, int C, void* stream);
+
+/* Spatial merge of compressed local tokens (llava_arch.py:235-244): in fp32 [n=nh*nw, g*g, C] ->
+ * out[dst_row0 + ((gy*g+qy)*nw + gx)*g + qx, :]; merge == 0 is the 'flat' order (:233-234). */
+int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, int nw, int nh, int g,
+                     int C, int merge, void* stream);
+
+/* Tile + normalise on device: canvas uint8 [Hc, Wc, 3] (Hc, Wc multiples of `crop`) -> T/fp32
+ * crops [ (Hc/crop)*(Wc/crop), 3, crop, crop ] in row-major tile order, value =
+ * (u8 * (1/255) - mean[c]) / std[c]  (divide_to_patches mm_utils.py:134-153 + CLIPImageProcessor
+ * rescale/normalize). */
+int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3_host,
+                         const float* std3_host, void* out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CLIP vision tower (CLIPVisionTower.forward + feature_select, clip_encoder.py:36-58)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int hidden, inter, heads, layers_run;   /* layers_run = layers that feed hidden_states[select_layer] */
+    int image, patch, kpad;                 /* kpad = 3*patch*patch rounded up to a multiple of 64       */
+    int dtype;                              /* SLIME_BF16 / SLIME_F16                                    */
+    float eps;
+    const void*  patch_w;                   /* T   [hidden, kpad]  (zero padded)                          */
+    const float* cls;                       /* f32 [hidden]                                               */
+    const float* pos;                       /* f32 [1+P, hidden]                                          */
+    const float* pre_ln_w; const float* pre_ln_b;
+    /* per-layer tensors, contiguous over layers (layer stride = the per-layer element count) */
+    const float* ln1_w; const float* ln1_b; /* f32 [L, hidden]                                            */
+    const void*  w_qkv;                     /* T   [L, 3*hidden, hidden], q rows pre-scaled by dh^-0.5    */
+    const float* b_qkv;                     /* f32 [L, 3*hidden]          (q part pre-scaled)             */
+    const void*  w_o;   const float* b_o;   /* T   [L, hidden, hidden]; f32 [L, hidden]                   */
+    const float* ln2_w; const float* ln2_b;
+    const void*  w_fc1; const float* b_fc1; /* T   [L, inter, hidden];  f32 [L, inter]                    */
+    const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                   */
+} slime_vit_desc;
+
+size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
+
+/* pixels [n,3,image,image] -> out [n, P(+1 if keep_cls), hidden] in out_dtype (BF16/F16/F32).
+ * If hidden_f32 is non-NULL it also receives the fp32 residual stream [n, 1+P, hidden]
+ * (the selected hidden state before the cls drop / cast). */
+int slime_vit_forward(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n_crops,
+                      void* out, int out_dtype, int keep_cls, float* hidden_f32,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Resampler (sampler.py:91-173) with kv_proj = proj = Identity, as post_qformer / GatedBlock.attn
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int dim, heads, n_query, n_kv, dtype;
+    float eps;
+    const void*  q_proj;                    /* T   [n_query, dim]: ((ln_q(query)+pos_embed) Wq^T + bq) * dh^-0.5, input independent */
+    const float* pos_k;                     /* f32 [n_kv, dim]: get_abs_pos(pos_embed, kv grid)           */
+    const float* ln_kv_w; const float* ln_kv_b;
+    const void*  w_k; const float* b_k;     /* T [dim, dim]; f32 [dim]                                    */
+    const void*  w_v; const float* b_v;
+    const void*  w_o; const float* b_o;
+    const float* ln_post_w; const float* ln_post_b;
+} slime_resampler_desc;
+
+size_t slime_resampler_workspace_bytes(const slime_resampler_desc* d, int n);
+
+/* x fp32 [n, n_kv, dim] (row stride ldx) -> out_f32 [n*n_query, dim] and/or out_t T [n*n_query, dim] */
+int slime_resampler_forward(const slime_resampler_desc* d, const float* x, int ldx, int n,
+                            float* out_f32, void* out_t, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * mm_projector (projector/builder.py): MLP and GatedBlock
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int in_dim, hidden, dtype;
+    const void* w1; const float* b1;        /* T [hidden, in_dim]                                         */
+    const void* w2; const float* b2;        /* T [hidden, hidden]                                         */
+} slime_mlp_desc;
+
+size_t slime_mlp_workspace_bytes(const slime_mlp_desc* d, int rows);
+
+/* Linear -> exact GELU -> Linear (projector/builder.py:53-57).  Input either x_t (T [rows,in_dim]) or,
+ * if x_t is NULL, x_f32 (cast to T first).  out fp32 [rows, hidden]. */
+int slime_mlp_forward(const slime_mlp_desc* d, const float* x_f32, const void* x_t, int rows,
+                      float* out, void* ws, size_t ws_bytes, void* stream);
+
+size_t slime_gated_workspace_bytes(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, int n);
+
+/* GatedBlock.forward full path (projector/builder.py:183-209) on x fp32 [n, 576, in_dim]:
+ * learnable_gated < 0 -> softmax-gated mix of E0 = mlp(x) and E1 = mlp(attn(x)); 0/1 -> that expert. */
+int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn,
+                        const float* w_gate /* f32 [in_dim, 2] */, int learnable_gated,
+                        const float* x, int n, float* out, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLIME_HIP_H */

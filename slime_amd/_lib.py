@@ -1,0 +1,128 @@
+"""ctypes binding of ``libslime_hip.so`` (C ABI declared in ``include/slime_hip.h``).
+
+There is deliberately NO fallback: if the HIP library is missing or does not export the ABI the
+import of a compute entry point raises.  (``tests/test_abi.py`` checks, without a GPU, that every
+symbol the header declares is exported.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslime_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
+CSRC = os.path.join(_HERE, "csrc")
+
+BF16, F16, F32, U8 = 0, 1, 2, 3
+EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = range(5)
+
+c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+
+
+class VitDesc(C.Structure):
+    _fields_ = [("hidden", c_int), ("inter", c_int), ("heads", c_int), ("layers_run", c_int),
+                ("image", c_int), ("patch", c_int), ("kpad", c_int), ("dtype", c_int), ("eps", c_float),
+                ("patch_w", c_void_p), ("cls", c_void_p), ("pos", c_void_p),
+                ("pre_ln_w", c_void_p), ("pre_ln_b", c_void_p),
+                ("ln1_w", c_void_p), ("ln1_b", c_void_p), ("w_qkv", c_void_p), ("b_qkv", c_void_p),
+                ("w_o", c_void_p), ("b_o", c_void_p), ("ln2_w", c_void_p), ("ln2_b", c_void_p),
+                ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p)]
+
+
+class ResamplerDesc(C.Structure):
+    _fields_ = [("dim", c_int), ("heads", c_int), ("n_query", c_int), ("n_kv", c_int), ("dtype", c_int),
+                ("eps", c_float), ("q_proj", c_void_p), ("pos_k", c_void_p),
+                ("ln_kv_w", c_void_p), ("ln_kv_b", c_void_p), ("w_k", c_void_p), ("b_k", c_void_p),
+                ("w_v", c_void_p), ("b_v", c_void_p), ("w_o", c_void_p), ("b_o", c_void_p),
+                ("ln_post_w", c_void_p), ("ln_post_b", c_void_p)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("in_dim", c_int), ("hidden", c_int), ("dtype", c_int),
+                ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p)]
+
+
+_P = C.POINTER
+_SIGNATURES = {
+    "slime_abi_version": (c_int, []),
+    "slime_last_error": (C.c_char_p, []),
+    "slime_gemm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "slime_im2col": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_embed_prenorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
+                                    c_int, c_int, c_void_p]),
+    "slime_attention": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
+                                c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_gate_mix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "slime_gather_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_merge_rows": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_tile_normalize": (c_int, [c_void_p, c_int, c_int, c_int, _P(c_float), _P(c_float), c_void_p, c_int, c_void_p]),
+    "slime_vit_workspace_bytes": (c_size_t, [_P(VitDesc), c_int]),
+    "slime_vit_forward": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "slime_resampler_workspace_bytes": (c_size_t, [_P(ResamplerDesc), c_int]),
+    "slime_resampler_forward": (c_int, [_P(ResamplerDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_size_t, c_void_p]),
+    "slime_mlp_workspace_bytes": (c_size_t, [_P(MlpDesc), c_int]),
+    "slime_mlp_forward": (c_int, [_P(MlpDesc), c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "slime_gated_workspace_bytes": (c_size_t, [_P(MlpDesc), _P(ResamplerDesc), c_int]),
+    "slime_gated_forward": (c_int, [_P(MlpDesc), _P(ResamplerDesc), c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    # tuning hooks (not part of the reference-facing ABI)
+    "slime_gemm_force_tile": (None, [c_int]),
+    "slime_gemm_set_sched": (None, [c_int]),
+}
+
+_lib = None
+
+
+class SlimeHipError(RuntimeError):
+    pass
+
+
+def header_symbols():
+    """Function names declared in include/slime_hip.h (used by the ABI test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slime_[a-z0-9_]+)\s*\(", text)))
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise SlimeHipError("building libslime_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """Load the library and bind prototypes; raises if it is missing (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlimeHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C slime_amd/csrc`.  slime_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    got = lib.slime_abi_version()
+    if got != 1:
+        raise SlimeHipError(f"libslime_hip ABI version {got}, expected 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().slime_last_error().decode("utf-8", "replace")
+        raise SlimeHipError(f"{what or 'libslime_hip'} failed (code {rc}): {msg}")

@@ -1,0 +1,298 @@
+// api.hip -- C-ABI drivers of libslime_hip: the CLIP tower layer loop, the Resampler, the projector
+// MLP and the GatedBlock, each a fixed sequence of the primitive kernels on one stream.  No
+// allocation, no synchronisation, no global mutable state: callable under hipGraph capture.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void slime_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* slime_last_error(void) { return g_err; }
+extern "C" int slime_abi_version(void) { return SLIME_ABI_VERSION; }
+
+#define TRY(call)                     \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != SLIME_OK) return rc_; \
+    } while (0)
+
+namespace {
+// bump allocator over the caller's workspace
+struct Arena {
+    char* base; size_t size; size_t off;
+    explicit Arena(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+    void* take(size_t bytes) {
+        const size_t o = align_up(off, 256);
+        off = o + bytes;
+        return (base && off <= size) ? base + o : nullptr;
+    }
+};
+static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// CLIP tower
+// ------------------------------------------------------------------------------------------------
+struct VitPlan {
+    size_t xn, qkv, ctx, ff, h, total;   // offsets
+};
+
+static VitPlan vit_plan(const slime_vit_desc* d, int n) {
+    const int g = d->image / d->patch, P = g * g, S = P + 1;
+    const size_t M = (size_t)n * S, Mp = (size_t)n * P, D = d->hidden;
+    VitPlan p{};
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
+    p.h = take(M * D * 4);
+    p.xn = take(M * D * 2);
+    p.qkv = take(M * 3 * D * 2);
+    p.ctx = take(M * D * 2);
+    // ff also hosts the patch-embed staging (im2col operand + fp32 conv output) before the layers
+    const size_t ff_bytes = M * (size_t)d->inter * 2;
+    const size_t pe_bytes = align_up(Mp * (size_t)d->kpad * 2, 256) + Mp * D * 4;
+    p.ff = take(ff_bytes > pe_bytes ? ff_bytes : pe_bytes);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+static int vit_validate(const slime_vit_desc* d) {
+    SLIME_REQUIRE(d, "vit: null descriptor");
+    SLIME_REQUIRE(is16(d->dtype), "vit: dtype must be BF16 or F16");
+    SLIME_REQUIRE(d->hidden == 128 || d->hidden == 256 || d->hidden == 1024, "vit: hidden=%d unsupported", d->hidden);
+    SLIME_REQUIRE(d->heads > 0 && d->hidden % d->heads == 0 && d->hidden / d->heads == 64, "vit: head_dim must be 64");
+    SLIME_REQUIRE(d->inter % 128 == 0 && d->inter % 64 == 0, "vit: intermediate size %d must be a multiple of 128", d->inter);
+    SLIME_REQUIRE(d->image % d->patch == 0, "vit: image %d not a multiple of patch %d", d->image, d->patch);
+    SLIME_REQUIRE(d->kpad % 64 == 0 && d->kpad >= 3 * d->patch * d->patch, "vit: kpad=%d", d->kpad);
+    SLIME_REQUIRE(d->layers_run >= 0, "vit: layers_run < 0");
+    SLIME_REQUIRE(d->patch_w && d->cls && d->pos && d->pre_ln_w && d->pre_ln_b, "vit: missing embedding weights");
+    SLIME_REQUIRE(d->layers_run == 0 || (d->ln1_w && d->ln1_b && d->w_qkv && d->b_qkv && d->w_o && d->b_o && d->ln2_w &&
+                                         d->ln2_b && d->w_fc1 && d->b_fc1 && d->w_fc2 && d->b_fc2), "vit: missing layer weights");
+    return SLIME_OK;
+}
+
+extern "C" size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops) {
+    if (!d || n_crops <= 0 || d->patch <= 0) return 0;
+    return vit_plan(d, n_crops).total;
+}
+
+extern "C" int slime_vit_forward(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out,
+                                 int out_dtype, int keep_cls, float* hidden_f32, void* ws, size_t ws_bytes,
+                                 void* stream) {
+    TRY(vit_validate(d));
+    SLIME_REQUIRE(pixels && n > 0, "vit: bad input");
+    SLIME_REQUIRE(out || hidden_f32, "vit: no output requested");
+    SLIME_REQUIRE(!out || out_dtype == SLIME_F32 || is16(out_dtype), "vit: bad out dtype");
+    const VitPlan p = vit_plan(d, n);
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
+        slime_set_error("vit: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, p.total);
+        return SLIME_EWORKSPACE;
+    }
+    const int g = d->image / d->patch, P = g * g, S = P + 1, D = d->hidden, F = d->inter;
+    const int M = n * S, Mp = n * P;
+    char* w = (char*)ws;
+    float* h = hidden_f32 ? hidden_f32 : (float*)(w + p.h);
+    void* xn = w + p.xn;
+    char* qkv = w + p.qkv;
+    void* ctx = w + p.ctx;
+    void* ff = w + p.ff;
+    void* a_pe = ff;
+    float* pe_out = (float*)((char*)ff + align_up((size_t)Mp * d->kpad * 2, 256));
+    const int dt = d->dtype;
+
+    // patch embed (conv as GEMM), class token, position table, pre-LayerNorm
+    TRY(slime_im2col(pixels, pix_dtype, a_pe, n, d->image, d->patch, d->kpad, dt, stream));
+    TRY(slime_gemm(a_pe, d->kpad, d->patch_w, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
+    TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, n, P, D, stream));
+
+    for (int l = 0; l < d->layers_run; ++l) {
+        const char* w_qkv = (const char*)d->w_qkv + (size_t)l * 3 * D * D * 2;
+        const char* w_o = (const char*)d->w_o + (size_t)l * D * D * 2;
+        const char* w_fc1 = (const char*)d->w_fc1 + (size_t)l * F * D * 2;
+        const char* w_fc2 = (const char*)d->w_fc2 + (size_t)l * D * F * 2;
+        TRY(slime_layernorm(h, D, M, D, d->ln1_w + (size_t)l * D, d->ln1_b + (size_t)l * D, d->eps, 1, nullptr, xn,
+                            nullptr, nullptr, 0, dt, stream));
+        TRY(slime_gemm(xn, D, w_qkv, d->b_qkv + (size_t)l * 3 * D, qkv, 3 * D, M, 3 * D, D, dt, SLIME_EPI_BIAS_T, stream));
+        TRY(slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
+                            qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
+                            dt, stream));
+        TRY(slime_gemm(ctx, D, w_o, d->b_o + (size_t)l * D, h, D, M, D, D, dt, SLIME_EPI_BIAS_RESID_F32, stream));
+        TRY(slime_layernorm(h, D, M, D, d->ln2_w + (size_t)l * D, d->ln2_b + (size_t)l * D, d->eps, 1, nullptr, xn,
+                            nullptr, nullptr, 0, dt, stream));
+        TRY(slime_gemm(xn, D, w_fc1, d->b_fc1 + (size_t)l * F, ff, F, M, F, D, dt, SLIME_EPI_BIAS_QUICKGELU_T, stream));
+        TRY(slime_gemm(ff, F, w_fc2, d->b_fc2 + (size_t)l * D, h, D, M, D, F, dt, SLIME_EPI_BIAS_RESID_F32, stream));
+    }
+    if (out) {
+        // feature_select: 'patch' drops the class token (clip_encoder.py:38-39), cast to out dtype (:52,56)
+        TRY(slime_gather_rows(h, S, keep_cls ? 0 : 1, out, out_dtype, n, keep_cls ? S : P, D, stream));
+    }
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resampler
+// ------------------------------------------------------------------------------------------------
+static int resampler_validate(const slime_resampler_desc* d) {
+    SLIME_REQUIRE(d, "resampler: null descriptor");
+    SLIME_REQUIRE(is16(d->dtype), "resampler: dtype must be BF16 or F16");
+    SLIME_REQUIRE(d->dim == 128 || d->dim == 256 || d->dim == 1024, "resampler: dim=%d unsupported", d->dim);
+    SLIME_REQUIRE(d->heads > 0 && d->dim % d->heads == 0, "resampler: heads");
+    const int dh = d->dim / d->heads;
+    SLIME_REQUIRE(dh == 64 || dh == 128, "resampler: head_dim %d unsupported", dh);
+    SLIME_REQUIRE(d->n_query > 0 && d->n_kv > 0, "resampler: empty query/key grid");
+    SLIME_REQUIRE(d->q_proj && d->pos_k && d->ln_kv_w && d->ln_kv_b && d->w_k && d->b_k && d->w_v && d->b_v &&
+                  d->w_o && d->b_o && d->ln_post_w && d->ln_post_b, "resampler: missing weights");
+    return SLIME_OK;
+}
+
+struct ResPlan { size_t xn, xk, kp, vp, ctx, o32, total; };
+static ResPlan res_plan(const slime_resampler_desc* d, int n) {
+    const size_t Rk = (size_t)n * d->n_kv, Rq = (size_t)n * d->n_query, D = d->dim;
+    ResPlan p{};
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
+    p.xn = take(Rk * D * 2); p.xk = take(Rk * D * 2); p.kp = take(Rk * D * 2); p.vp = take(Rk * D * 2);
+    p.ctx = take(Rq * D * 2); p.o32 = take(Rq * D * 4);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+extern "C" size_t slime_resampler_workspace_bytes(const slime_resampler_desc* d, int n) {
+    if (!d || n <= 0) return 0;
+    return res_plan(d, n).total;
+}
+
+extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const float* x, int ldx, int n, float* out_f32,
+                                       void* out_t, void* ws, size_t ws_bytes, void* stream) {
+    TRY(resampler_validate(d));
+    SLIME_REQUIRE(x && n > 0 && ldx >= d->dim, "resampler: bad input");
+    SLIME_REQUIRE(out_f32 || out_t, "resampler: no output requested");
+    const ResPlan p = res_plan(d, n);
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
+        slime_set_error("resampler: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, p.total);
+        return SLIME_EWORKSPACE;
+    }
+    char* w = (char*)ws;
+    const int D = d->dim, Rk = n * d->n_kv, Rq = n * d->n_query, dh = D / d->heads, dt = d->dtype;
+    // x = ln_kv(x); K input = x + pos (sampler.py:158,164); V input = x
+    TRY(slime_layernorm(x, ldx, Rk, D, d->ln_kv_w, d->ln_kv_b, d->eps, 1, nullptr, w + p.xn, w + p.xk, d->pos_k,
+                        d->n_kv, dt, stream));
+    TRY(slime_gemm(w + p.xk, D, d->w_k, d->b_k, w + p.kp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
+    TRY(slime_gemm(w + p.xn, D, d->w_v, d->b_v, w + p.vp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
+    TRY(slime_attention(d->q_proj, 0, D, w + p.kp, (long)d->n_kv * D, D, w + p.vp, (long)d->n_kv * D, D, w + p.ctx,
+                        (long)d->n_query * D, D, n, d->heads, dh, d->n_query, d->n_kv, dt, stream));
+    TRY(slime_gemm(w + p.ctx, D, d->w_o, d->b_o, w + p.o32, D, Rq, D, D, dt, SLIME_EPI_BIAS_F32, stream));
+    TRY(slime_layernorm((const float*)(w + p.o32), D, Rq, D, d->ln_post_w, d->ln_post_b, d->eps, 1, out_f32, out_t,
+                        nullptr, nullptr, 0, dt, stream));
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Projector MLP
+// ------------------------------------------------------------------------------------------------
+static int mlp_validate(const slime_mlp_desc* d) {
+    SLIME_REQUIRE(d, "mlp: null descriptor");
+    SLIME_REQUIRE(is16(d->dtype), "mlp: dtype must be BF16 or F16");
+    SLIME_REQUIRE(d->in_dim == 128 || d->in_dim == 256 || d->in_dim == 1024, "mlp: in_dim=%d unsupported", d->in_dim);
+    SLIME_REQUIRE(d->hidden % 128 == 0, "mlp: hidden=%d must be a multiple of 128", d->hidden);
+    SLIME_REQUIRE(d->w1 && d->b1 && d->w2 && d->b2, "mlp: missing weights");
+    return SLIME_OK;
+}
+
+struct MlpPlan { size_t xt, mid, total; };
+static MlpPlan mlp_plan(const slime_mlp_desc* d, int rows) {
+    MlpPlan p{};
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
+    p.xt = take((size_t)rows * d->in_dim * 2);
+    p.mid = take((size_t)rows * d->hidden * 2);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+extern "C" size_t slime_mlp_workspace_bytes(const slime_mlp_desc* d, int rows) {
+    if (!d || rows <= 0) return 0;
+    return mlp_plan(d, rows).total;
+}
+
+extern "C" int slime_mlp_forward(const slime_mlp_desc* d, const float* x_f32, const void* x_t, int rows, float* out,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    TRY(mlp_validate(d));
+    SLIME_REQUIRE((x_f32 || x_t) && out && rows > 0, "mlp: bad input");
+    const MlpPlan p = mlp_plan(d, rows);
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
+        slime_set_error("mlp: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, p.total);
+        return SLIME_EWORKSPACE;
+    }
+    char* w = (char*)ws;
+    const void* a = x_t;
+    if (!a) {
+        TRY(slime_layernorm(x_f32, d->in_dim, rows, d->in_dim, nullptr, nullptr, 0.f, 0, nullptr, w + p.xt, nullptr,
+                            nullptr, 0, d->dtype, stream));
+        a = w + p.xt;
+    }
+    TRY(slime_gemm(a, d->in_dim, d->w1, d->b1, w + p.mid, d->hidden, rows, d->hidden, d->in_dim, d->dtype,
+                   SLIME_EPI_BIAS_GELU_T, stream));
+    TRY(slime_gemm(w + p.mid, d->hidden, d->w2, d->b2, out, d->hidden, rows, d->hidden, d->hidden, d->dtype,
+                   SLIME_EPI_BIAS_F32, stream));
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GatedBlock
+// ------------------------------------------------------------------------------------------------
+struct GatedPlan { size_t e0, e1, rt, mlp, res, total; };
+static GatedPlan gated_plan(const slime_mlp_desc* m, const slime_resampler_desc* r, int n) {
+    const size_t rows = (size_t)n * r->n_query;
+    GatedPlan p{};
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
+    p.e0 = take(rows * m->hidden * 4);
+    p.e1 = take(rows * m->hidden * 4);
+    p.rt = take(rows * m->in_dim * 2);
+    p.mlp = take(mlp_plan(m, (int)rows).total);
+    p.res = take(res_plan(r, n).total);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+extern "C" size_t slime_gated_workspace_bytes(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, int n) {
+    if (!mlp || !attn || n <= 0) return 0;
+    return gated_plan(mlp, attn, n).total;
+}
+
+extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, const float* w_gate,
+                                   int learnable_gated, const float* x, int n, float* out, void* ws, size_t ws_bytes,
+                                   void* stream) {
+    TRY(mlp_validate(mlp));
+    TRY(resampler_validate(attn));
+    SLIME_REQUIRE(x && out && n > 0, "gated: bad input");
+    SLIME_REQUIRE(attn->dim == mlp->in_dim && attn->n_query == attn->n_kv, "gated: attn must map the token grid onto itself");
+    SLIME_REQUIRE(learnable_gated >= 0 || w_gate, "gated: missing w_gate");
+    SLIME_REQUIRE(learnable_gated <= 1, "gated: expert index %d", learnable_gated);
+    const GatedPlan p = gated_plan(mlp, attn, n);
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
+        slime_set_error("gated: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, p.total);
+        return SLIME_EWORKSPACE;
+    }
+    char* w = (char*)ws;
+    const int rows = n * attn->n_query;
+    const size_t mlp_ws = mlp_plan(mlp, rows).total, res_ws = res_plan(attn, n).total;
+    float* e0 = learnable_gated == 0 ? out : (float*)(w + p.e0);
+    float* e1 = learnable_gated == 1 ? out : (float*)(w + p.e1);
+    if (learnable_gated != 1)                                   // expert 0: projection(x)
+        TRY(slime_mlp_forward(mlp, x, nullptr, rows, e0, w + p.mlp, mlp_ws, stream));
+    if (learnable_gated != 0) {                                 // expert 1: projection(attn(x))
+        TRY(slime_resampler_forward(attn, x, attn->dim, n, nullptr, w + p.rt, w + p.res, res_ws, stream));
+        TRY(slime_mlp_forward(mlp, nullptr, w + p.rt, rows, e1, w + p.mlp, mlp_ws, stream));
+    }
+    if (learnable_gated < 0)
+        TRY(slime_gate_mix(x, mlp->in_dim, w_gate, e0, e1, out, rows, mlp->hidden, stream));
+    return SLIME_OK;
+}

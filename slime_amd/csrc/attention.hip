@@ -1,0 +1,280 @@
+// attention.hip -- fused softmax(Q K^T) V for gfx950, head_dim 64 (CLIP-ViT self-attention, S = 577)
+// and 128 (Resampler cross-attention, 144/576 queries x 576 keys).
+//
+// One workgroup owns one (batch item, head) [x q-split]; its K and V panels live in LDS
+// (the whole 577 x 64 K and V of a CLIP head are 2 x 76 KiB -- they fit the 160 KiB LDS, so they are
+// read from HBM/L2 exactly once per workgroup and there is no staging pipeline in the main loop;
+// head_dim 128 uses kv chunks of 288 rows).  Queries are split in 16-row sub-blocks that are dealt to
+// the waves (577 -> 37 sub-blocks -> 5,5,5,5,5,4,4,4); a wave keeps all its sub-blocks in flight so
+// every K/V fragment read from LDS feeds NSUB MFMAs.
+//
+// Everything is computed TRANSPOSED (the "swapped QK^T" form):
+//   S^T[kv,q] = K Q^T      mfma(A = K rows from LDS (ds_read_b128), B = Q rows held in VGPRs)
+//   O^T[d,q]  = V^T P^T    mfma(A = V^T via ds_read_b64_tr_b16 (hardware transpose), B = P^T)
+// With the 16x16x32 C/D layout (col = lane&15, row = 4*(lane>>4)+r) a lane owns ONE query column:
+// running max / sum / rescale factors are lane-local scalars, and the fp32 S^T tile a lane holds is
+// -- after exp and a 16-bit pack -- bit-for-bit the B operand of the PV MFMA (k-slot order
+// {tile0: 4g+0..3, tile1: 4g+0..3}, matched by the two transpose reads of V).  P never touches LDS.
+//
+// LDS images: K rows are 16-B-chunk XOR-swizzled for conflict-free ds_read_b128; V rows are swizzled
+// at 8-B granularity so that the 8 rows x 4 pieces a half-wave transpose-read touches cover all 64
+// banks.  Softmax statistics are fp32; exp via v_exp_f32 (exp2) on log2e-scaled scores.
+#include "common.h"
+
+struct AttnArgs {
+    const char* q; long q_bs, q_rs;
+    const char* k; long k_bs, k_rs;
+    const char* v; long v_bs, v_rs;
+    char* o; long o_bs, o_rs;
+    int heads, n_q, n_kv, sb_per_wg;
+};
+
+template <int DH> __device__ __forceinline__ int v_swizzle(int row) {
+    if constexpr (DH == 64) return ((row >> 1) & 1) | (((row >> 2) & 1) << 3);
+    else return (row & 1) | (((row >> 1) & 3) << 3);
+}
+
+__device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4i16_ptr;
+    s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_ptr)LDS_PTR(p));
+    return __builtin_bit_cast(u32x2, r);
+}
+
+template <typename T, int DH, int KC, int NW, int NSUB>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
+    constexpr int RB = DH * 2;            // bytes per K/V row
+    constexpr int CPR = DH / 8;           // 16-B chunks per row
+    constexpr int KS = DH / 32;           // k-steps of the QK^T contraction
+    constexpr int DT = DH / 16;           // 16-row tiles of O^T
+    constexpr int NT = NW * 64;
+    constexpr float LOG2E = 1.4426950408889634f;
+    char* Klds = smem;
+    char* Vlds = smem + KC * RB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = lane >> 4, li = lane & 15;
+
+    const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
+    const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane holds q-row li, d = ks*32 + 8g .. +7 -------
+    u32x4 qf[NSUB > 0 ? NSUB : 1][KS];
+    if constexpr (NSUB > 0) {
+        const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[s][ks] = *reinterpret_cast<const u32x4*>(qbase + ((size_t)qr * a.q_rs + ks * 32 + g * 8) * 2);
+        }
+    }
+    f32x4 o[NSUB > 0 ? NSUB : 1][DT];
+    float m_run[NSUB > 0 ? NSUB : 1], l_run[NSUB > 0 ? NSUB : 1];
+#pragma unroll
+    for (int s = 0; s < (NSUB > 0 ? NSUB : 1); ++s) {
+        m_run[s] = -INFINITY; l_run[s] = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) o[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // per-lane LDS offsets
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = li * RB + (((ks * 4 + g) ^ (lane & (CPR - 1))) << 4);
+    int voff[DT];
+    {
+        const int vrow = 4 * g + (li >> 2);
+        const int sw = v_swizzle<DH>(vrow);                 // depends on (row mod 16) only
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int e = 8 * (dt >> 1) + 2 * (li & 3) + (dt & 1);
+            voff[dt] = vrow * RB + ((e ^ sw) << 3);
+        }
+    }
+
+    for (int kv0 = 0; kv0 < a.n_kv; kv0 += KC) {
+        if (kv0 > 0) __syncthreads();                       // previous chunk fully consumed
+        // ---- stage K and V chunk: global (16 B/lane) -> registers -> swizzled LDS ---------------
+        {
+            constexpr int TOTAL = KC * CPR;
+            constexpr int U = 5;
+            for (int base = 0; base < TOTAL; base += NT * U) {
+                u32x4 kk[U], vv[U];
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int idx = base + j * NT + tid;
+                    const int r = idx / CPR, u = idx % CPR;
+                    const int gr = kv0 + r;
+                    kk[j] = u32x4{0u, 0u, 0u, 0u}; vv[j] = u32x4{0u, 0u, 0u, 0u};
+                    if (idx < TOTAL && gr < a.n_kv) {
+                        kk[j] = *reinterpret_cast<const u32x4*>(kbase + ((size_t)gr * a.k_rs) * 2 + u * 16);
+                        vv[j] = *reinterpret_cast<const u32x4*>(vbase + ((size_t)gr * a.v_rs) * 2 + u * 16);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < U; ++j) {
+                    const int idx = base + j * NT + tid;
+                    if (idx < TOTAL) {
+                        const int r = idx / CPR, u = idx % CPR;
+                        *reinterpret_cast<u32x4*>(Klds + r * RB + ((u ^ (r & (CPR - 1))) << 4)) = kk[j];
+                        const int sw = v_swizzle<DH>(r);
+                        u32x4 w = vv[j];
+                        if (sw & 1) w = u32x4{vv[j][2], vv[j][3], vv[j][0], vv[j][1]};
+                        *reinterpret_cast<u32x4*>(Vlds + r * RB + ((u ^ (sw >> 1)) << 4)) = w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        if constexpr (NSUB > 0) {
+            const int rows = min(KC, a.n_kv - kv0);
+            const int steps = (rows + 31) >> 5;
+            for (int st = 0; st < steps; ++st) {
+                const char* kp = Klds + st * 32 * RB;
+                const char* vp = Vlds + st * 32 * RB;
+                // ---- S^T tiles: 2 x (16 kv) per sub-block ------------------------------------------
+                f32x4 sc[NSUB][2];
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) { sc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const u32x4 kf = *reinterpret_cast<const u32x4*>(kp + t * 16 * RB + koff[ks]);
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf, qf[s][ks], sc[s][t]);
+                    }
+                if (kv0 + st * 32 + 32 > a.n_kv) {          // ragged tail: mask kv >= n_kv
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool dead = kv0 + st * 32 + t * 16 + 4 * g + r >= a.n_kv;
+#pragma unroll
+                            for (int s = 0; s < NSUB; ++s) if (dead) sc[s][t][r] = -INFINITY;
+                        }
+                }
+                // ---- online softmax (lane-local: one q column per lane) ---------------------------
+                u32x4 pf[NSUB];
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) {
+                    float mx = fmaxf(fmaxf(fmaxf(sc[s][0][0], sc[s][0][1]), fmaxf(sc[s][0][2], sc[s][0][3])),
+                                     fmaxf(fmaxf(sc[s][1][0], sc[s][1][1]), fmaxf(sc[s][1][2], sc[s][1][3])));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float m_new = fmaxf(m_run[s], mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);
+                    const float mneg = -m_new * LOG2E;
+                    float p[8];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[s][t][r], LOG2E, mneg));
+                    l_run[s] = l_run[s] * alpha + ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    m_run[s] = m_new;
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) o[s][d] *= alpha;
+                    pf[s] = pack8<T>(p);
+                }
+                // ---- O^T += V^T P^T ----------------------------------------------------------------
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const u32x2 v0 = lds_read_tr16(vp + voff[dt]);
+                    const u32x2 v1 = lds_read_tr16(vp + 16 * RB + voff[dt]);
+                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) o[s][dt] = T::mfma16(vf, pf[s], o[s][dt]);
+                }
+            }
+        }
+    }
+
+    // ---- finalize: 1/l, 16-B stores of 8 consecutive d per lane ---------------------------------
+    if constexpr (NSUB > 0) {
+        char* obase = a.o + ((size_t)b * a.o_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            float l = l_run[s];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            const float inv = 1.0f / l;
+            const int qr = (sb0 + s) * 16 + li;
+            if (qr < a.n_q) {
+#pragma unroll
+                for (int p = 0; p < DT / 2; ++p) {
+                    float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
+                                  o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
+                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int DH, int KC, int NW, int NSUBMAX>
+__global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_sb = (a.n_q + 15) >> 4;
+    const int wg_sb0 = blockIdx.z * a.sb_per_wg;
+    const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);
+    const int base = nsb / NW, rem = nsb % NW;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int sb0 = wg_sb0 + wave * base + min(wave, rem);
+    switch (cnt) {
+        case 0: attn_body<T, DH, KC, NW, 0>(a, smem, b, h, sb0); break;
+        case 1: attn_body<T, DH, KC, NW, 1>(a, smem, b, h, sb0); break;
+        case 2: attn_body<T, DH, KC, NW, 2>(a, smem, b, h, sb0); break;
+        case 3: attn_body<T, DH, KC, NW, 3>(a, smem, b, h, sb0); break;
+        default:
+            if constexpr (NSUBMAX >= 5) {
+                if (cnt == 4) attn_body<T, DH, KC, NW, 4>(a, smem, b, h, sb0);
+                else attn_body<T, DH, KC, NW, 5>(a, smem, b, h, sb0);
+            }
+            break;
+    }
+}
+
+template <typename T, int DH, int KC, int NW, int NSUBMAX>
+static int launch_attn(const AttnArgs& a0, int batch, hipStream_t stream) {
+    AttnArgs a = a0;
+    constexpr int LDS = 2 * KC * DH * 2;
+    auto kern = attn_kernel<T, DH, KC, NW, NSUBMAX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    const int total_sb = (a.n_q + 15) / 16;
+    const int cap = NW * NSUBMAX;
+    const int qsplit = (total_sb + cap - 1) / cap;
+    a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
+    hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(NW * 64), LDS, stream, a);
+    SLIME_CHECK_LAUNCH("attention");
+    return SLIME_OK;
+}
+
+extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
+                               const void* v, long v_bs, long v_rs, void* o, long o_bs, long o_rs,
+                               int batch, int heads, int head_dim, int n_q, int n_kv, int dtype, void* stream) {
+    SLIME_REQUIRE(q && k && v && o, "attention: null pointer");
+    SLIME_REQUIRE(batch > 0 && heads > 0 && n_q > 0 && n_kv > 0, "attention: empty shape");
+    SLIME_REQUIRE(head_dim == 64 || head_dim == 128, "attention: head_dim %d unsupported (64, 128)", head_dim);
+    SLIME_REQUIRE(q_rs % 8 == 0 && k_rs % 8 == 0 && v_rs % 8 == 0 && o_rs % 8 == 0 &&
+                  q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0, "attention: strides must be multiples of 8 elements");
+    SLIME_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: pointers must be 16-byte aligned");
+    SLIME_REQUIRE(batch <= 65535, "attention: batch %d exceeds grid.y", batch);
+    AttnArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs,
+               (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64) {
+        // K+V resident up to 608 rows (CLIP S = 577); longer sequences stream in 608-row chunks.
+        if (dtype == SLIME_F16) return launch_attn<F16, 64, 608, 8, 5>(a, batch, s);
+        return launch_attn<BF16, 64, 608, 8, 5>(a, batch, s);
+    }
+    if (dtype == SLIME_F16) return launch_attn<F16, 128, 288, 6, 3>(a, batch, s);
+    return launch_attn<BF16, 128, 288, 6, 3>(a, batch, s);
+}

@@ -1,0 +1,84 @@
+// common.h -- shared device helpers for libslime_hip (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "slime_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-bit MFMA operand types.  `bits` are carried around as raw u32 words.
+struct BF16 {
+    static constexpr int id = SLIME_BF16;
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                      __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // RNE
+    }
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+};
+struct F16 {
+    static constexpr int id = SLIME_F16;
+    static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                     __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
+        f32x2 v = {lo, hi};
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));    // RNE
+    }
+    static __device__ __forceinline__ float lo(unsigned w) {
+        return (float)__builtin_bit_cast(f16x2_t, w)[0];
+    }
+    static __device__ __forceinline__ float hi(unsigned w) {
+        return (float)__builtin_bit_cast(f16x2_t, w)[1];
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+    u32x4 r;
+    r[0] = T::pack2(v[0], v[1]); r[1] = T::pack2(v[2], v[3]);
+    r[2] = T::pack2(v[4], v[5]); r[3] = T::pack2(v[6], v[7]);
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- host side error plumbing ------------------------------------------------------------------
+void slime_set_error(const char* fmt, ...);
+
+#define SLIME_REQUIRE(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) { slime_set_error(__VA_ARGS__); return SLIME_EINVAL; } \
+    } while (0)
+
+#define SLIME_CHECK_LAUNCH(what)                                                     \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            slime_set_error("%s: %s", what, hipGetErrorString(e_));                  \
+            return SLIME_ELAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,371 @@
+// rowwise.hip -- HBM-bound row kernels: LayerNorm (+cast/+position term), im2col for the patch
+// embed, cls/pos/pre-LN embedding assembly, gate mix, row gather / spatial merge, tile+normalise.
+// One wave (64 lanes) owns one row; loads are 16 B/lane (float4) wherever the width allows.
+#include "common.h"
+
+template <typename T> __device__ __forceinline__ unsigned short to_t1(float x) {
+    return (unsigned short)(T::pack2(x, 0.f) & 0xffffu);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over fp32 rows; VPL = values per lane (D = 64*VPL).  Two-pass variance in registers.
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+    const float* x; int ldx; int rows;
+    const float* w; const float* b; float eps; int normalize;
+    float* out_f32; void* out_t; void* out_t2; const float* add; int add_period;
+};
+
+template <typename T, int VPL>
+__global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
+    constexpr int D = 64 * VPL;
+    constexpr int VEC = (VPL >= 4) ? 4 : 2;          // floats per load
+    constexpr int NV = VPL / VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* xr = a.x + (size_t)row * a.ldx;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xr + c);
+            v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+        } else {
+            const float2 t = *reinterpret_cast<const float2*>(xr + c);
+            v[i * 2 + 0] = t.x; v[i * 2 + 1] = t.y;
+        }
+    }
+    if (a.normalize) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) s += v[i];
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                v[i * VEC + j] = (v[i * VEC + j] - mean) * rstd * a.w[c + j] + a.b[c + j];
+        }
+    }
+    const float* addr = a.out_t2 ? a.add + (size_t)(row % a.add_period) * D : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+        if (a.out_f32) {
+            float* o = a.out_f32 + (size_t)row * D + c;
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
+            else *reinterpret_cast<float2*>(o) = make_float2(v[i * 2], v[i * 2 + 1]);
+        }
+        if (a.out_t) {
+            char* o = reinterpret_cast<char*>(a.out_t) + ((size_t)row * D + c) * 2;
+            if constexpr (VEC == 4) {
+                u32x2 p = {T::pack2(v[i * 4], v[i * 4 + 1]), T::pack2(v[i * 4 + 2], v[i * 4 + 3])};
+                *reinterpret_cast<u32x2*>(o) = p;
+            } else {
+                *reinterpret_cast<unsigned*>(o) = T::pack2(v[i * 2], v[i * 2 + 1]);
+            }
+        }
+        if (a.out_t2) {
+            char* o = reinterpret_cast<char*>(a.out_t2) + ((size_t)row * D + c) * 2;
+            if constexpr (VEC == 4) {
+                u32x2 p = {T::pack2(v[i * 4] + addr[c], v[i * 4 + 1] + addr[c + 1]),
+                           T::pack2(v[i * 4 + 2] + addr[c + 2], v[i * 4 + 3] + addr[c + 3])};
+                *reinterpret_cast<u32x2*>(o) = p;
+            } else {
+                *reinterpret_cast<unsigned*>(o) = T::pack2(v[i * 2] + addr[c], v[i * 2 + 1] + addr[c + 1]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_ln(const LnArgs& a, int D, hipStream_t s) {
+    const dim3 grid((a.rows + 3) / 4), block(256);
+    switch (D) {
+        case 128: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, a); break;
+        case 256: hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, s, a); break;
+        case 1024: hipLaunchKernelGGL((layernorm_kernel<T, 16>), grid, block, 0, s, a); break;
+        default: slime_set_error("layernorm: D=%d unsupported (128, 256, 1024)", D); return SLIME_EINVAL;
+    }
+    SLIME_CHECK_LAUNCH("layernorm");
+    return SLIME_OK;
+}
+
+extern "C" int slime_layernorm(const float* x, int ldx, int rows, int D, const float* w, const float* b,
+                               float eps, int normalize, float* out_f32, void* out_t, void* out_t2,
+                               const float* add, int add_period, int dtype, void* stream) {
+    SLIME_REQUIRE(x && rows > 0 && ldx >= D, "layernorm: bad input");
+    SLIME_REQUIRE(!normalize || (w && b), "layernorm: missing affine parameters");
+    SLIME_REQUIRE(!out_t2 || (add && add_period > 0), "layernorm: out_t2 needs add/add_period");
+    SLIME_REQUIRE(ldx % 4 == 0, "layernorm: ldx must be a multiple of 4");
+    LnArgs a{x, ldx, rows, w, b, eps, normalize, out_f32, out_t, out_t2, add, add_period};
+    if (dtype == SLIME_F16) return launch_ln<F16>(a, D, (hipStream_t)stream);
+    return launch_ln<BF16>(a, D, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// im2col: one thread per 8-column chunk of the [n*g*g, kpad] operand; column k = (c, ky, kx).
+// Pixels are tiny (0.7-1.4 MB/crop) and stay L2-resident; the writes are 16 B/lane coalesced.
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename PixT>
+__global__ void __launch_bounds__(256) im2col_kernel(const PixT* px, unsigned short* out, int n, int image,
+                                                     int patch, int kpad) {
+    const int g = image / patch, pp = patch * patch, kreal = 3 * pp, chunks = kpad / 8;
+    const long total = (long)n * g * g * chunks;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % chunks);
+        const long row = idx / chunks;
+        const int pxi = (int)(row % g), pyi = (int)((row / g) % g), crop = (int)(row / ((long)g * g));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ch * 8 + j;
+            if (k < kreal) {
+                const int c = k / pp, r = k % pp, ky = r / patch, kx = r % patch;
+                const size_t off = (((size_t)crop * 3 + c) * image + (pyi * patch + ky)) * image + (pxi * patch + kx);
+                if constexpr (sizeof(PixT) == 4) v[j] = reinterpret_cast<const float*>(px)[off];
+                else {
+                    const unsigned w = reinterpret_cast<const unsigned short*>(px)[off];
+                    v[j] = T::lo(w);     // pixels already in T when 16-bit (checked on the host)
+                }
+            } else v[j] = 0.f;
+        }
+        *reinterpret_cast<u32x4*>(out + row * kpad + ch * 8) = pack8<T>(v);
+    }
+}
+
+extern "C" int slime_im2col(const void* pixels, int pix_dtype, void* out, int n, int image, int patch,
+                            int kpad, int dtype, void* stream) {
+    SLIME_REQUIRE(pixels && out && n > 0, "im2col: bad input");
+    SLIME_REQUIRE(image % patch == 0 && kpad % 8 == 0 && kpad >= 3 * patch * patch, "im2col: bad geometry");
+    SLIME_REQUIRE(pix_dtype == SLIME_F32 || pix_dtype == dtype, "im2col: 16-bit pixels must already be in the tower dtype");
+    const int g = image / patch;
+    const long total = (long)n * g * g * (kpad / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* o = (unsigned short*)out;
+    if (dtype == SLIME_F16) {
+        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<F16, float>), dim3(blocks), dim3(256), 0, s, (const float*)pixels, o, n, image, patch, kpad);
+        else hipLaunchKernelGGL((im2col_kernel<F16, unsigned short>), dim3(blocks), dim3(256), 0, s, (const unsigned short*)pixels, o, n, image, patch, kpad);
+    } else {
+        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<BF16, float>), dim3(blocks), dim3(256), 0, s, (const float*)pixels, o, n, image, patch, kpad);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, unsigned short>), dim3(blocks), dim3(256), 0, s, (const unsigned short*)pixels, o, n, image, patch, kpad);
+    }
+    SLIME_CHECK_LAUNCH("im2col");
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// h[n, 1+P, D] = pre_layrnorm(cat(cls, patch_out) + pos)
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ void __launch_bounds__(256) embed_prenorm_kernel(const float* patch_out, const float* cls, const float* pos,
+                                                            const float* w, const float* b, float eps, float* h,
+                                                            int n, int P) {
+    constexpr int D = 64 * VPL;
+    constexpr int VEC = (VPL >= 4) ? 4 : 2;
+    constexpr int NV = VPL / VEC;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)n * (P + 1)) return;
+    const int t = (int)(row % (P + 1));
+    const long crop = row / (P + 1);
+    const float* src = t == 0 ? cls : patch_out + (crop * P + (t - 1)) * D;
+    const float* pr = pos + (size_t)t * D;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[i * VEC + j] = src[c + j] + pr[c + j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += v[i];
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    float* o = h + row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[c + j] = (v[i * VEC + j] - mean) * rstd * w[c + j] + b[c + j];
+    }
+}
+
+extern "C" int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
+                                   const float* ln_b, float eps, float* h, int n, int P, int D, void* stream) {
+    SLIME_REQUIRE(patch_out && cls && pos && ln_w && ln_b && h && n > 0 && P > 0, "embed_prenorm: bad input");
+    const long rows = (long)n * (P + 1);
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (D) {
+        case 128: hipLaunchKernelGGL((embed_prenorm_kernel<2>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
+        case 256: hipLaunchKernelGGL((embed_prenorm_kernel<4>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
+        case 1024: hipLaunchKernelGGL((embed_prenorm_kernel<16>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
+        default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
+    }
+    SLIME_CHECK_LAUNCH("embed_prenorm");
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gate mix: (g0,g1) = softmax(x @ w_gate) / (sum + 1e-6);  out = g0*e0 + g1*e1.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gate_mix_kernel(const float* x, int D, const float* wg, const float* e0,
+                                                       const float* e1, float* out, int rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float l0 = 0.f, l1 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xv = xr[c];
+        const float2 w = *reinterpret_cast<const float2*>(wg + 2 * c);
+        l0 += xv * w.x; l1 += xv * w.y;
+    }
+    l0 = wave_sum(l0); l1 = wave_sum(l1);
+    const float m = fmaxf(l0, l1);
+    const float p0 = expf(l0 - m), p1 = expf(l1 - m);
+    const float ps = p0 + p1;
+    const float s0 = p0 / ps, s1 = p1 / ps;            // softmax
+    const float den = s0 + s1 + 1e-6f;                 // top-2-of-2 renormalisation
+    const float g0 = s0 / den, g1 = s1 / den;
+    const float* a = e0 + (size_t)row * H;
+    const float* b = e1 + (size_t)row * H;
+    float* o = out + (size_t)row * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        const float4 u = *reinterpret_cast<const float4*>(a + c);
+        const float4 w = *reinterpret_cast<const float4*>(b + c);
+        *reinterpret_cast<float4*>(o + c) = make_float4(g0 * u.x + g1 * w.x, g0 * u.y + g1 * w.y,
+                                                        g0 * u.z + g1 * w.z, g0 * u.w + g1 * w.w);
+    }
+}
+
+extern "C" int slime_gate_mix(const float* x, int D, const float* w_gate, const float* e0, const float* e1,
+                              float* out, int rows, int H, void* stream) {
+    SLIME_REQUIRE(x && w_gate && e0 && e1 && out && rows > 0 && H % 4 == 0, "gate_mix: bad input");
+    hipLaunchKernelGGL(gate_mix_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate, e0, e1, out, rows, H);
+    SLIME_CHECK_LAUNCH("gate_mix");
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row gather / spatial merge with cast.  One wave per output row, 4 floats per lane per step.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store_row_cast(const float* src, void* dst_base, size_t dst_row, int C, int out_dtype, int lane) {
+    if (out_dtype == SLIME_F32) {
+        float* d = reinterpret_cast<float*>(dst_base) + dst_row * C;
+        for (int c = lane * 4; c < C; c += 256) *reinterpret_cast<float4*>(d + c) = *reinterpret_cast<const float4*>(src + c);
+    } else {
+        char* d = reinterpret_cast<char*>(dst_base) + dst_row * C * 2;
+        for (int c = lane * 4; c < C; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(src + c);
+            u32x2 p = {T::pack2(t.x, t.y), T::pack2(t.z, t.w)};
+            *reinterpret_cast<u32x2*>(d + (size_t)c * 2) = p;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* in, int rows_in, int row_off, void* out,
+                                                          int out_dtype, long total, int rows_out, int C) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= total) return;
+    const long g = r / rows_out, i = r % rows_out;
+    const float* src = in + ((size_t)g * rows_in + row_off + i) * C;
+    if (out_dtype == SLIME_F16) store_row_cast<F16>(src, out, (size_t)r, C, out_dtype, lane);
+    else store_row_cast<BF16>(src, out, (size_t)r, C, out_dtype, lane);
+}
+
+extern "C" int slime_gather_rows(const float* in, int rows_in, int row_off, void* out, int out_dtype, int groups,
+                                 int rows_out, int C, void* stream) {
+    SLIME_REQUIRE(in && out && groups > 0 && rows_out > 0 && C % 4 == 0, "gather_rows: bad input");
+    SLIME_REQUIRE(row_off >= 0 && row_off + rows_out <= rows_in, "gather_rows: window outside the group");
+    const long total = (long)groups * rows_out;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       in, rows_in, row_off, out, out_dtype, total, rows_out, C);
+    SLIME_CHECK_LAUNCH("gather_rows");
+    return SLIME_OK;
+}
+
+__global__ void __launch_bounds__(256) merge_rows_kernel(const float* in, void* out, int out_dtype, long dst_row0,
+                                                         int nw, int nh, int g, int C, int merge) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // input row: (crop k, qy, qx)
+    const long total = (long)nw * nh * g * g;
+    if (r >= total) return;
+    long dst = r;
+    if (merge) {
+        const int qx = (int)(r % g), qy = (int)((r / g) % g), k = (int)(r / ((long)g * g));
+        const int gx = k % nw, gy = k / nw;
+        dst = ((long)(gy * g + qy) * nw + gx) * g + qx;
+    }
+    const float* src = in + (size_t)r * C;
+    if (out_dtype == SLIME_F16) store_row_cast<F16>(src, out, (size_t)(dst_row0 + dst), C, out_dtype, lane);
+    else store_row_cast<BF16>(src, out, (size_t)(dst_row0 + dst), C, out_dtype, lane);
+}
+
+extern "C" int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, int nw, int nh, int g,
+                                int C, int merge, void* stream) {
+    SLIME_REQUIRE(in && out && nw > 0 && nh > 0 && g > 0 && C % 4 == 0, "merge_rows: bad input");
+    const long total = (long)nw * nh * g * g;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, out_dtype, dst_row0, nw, nh, g, C, merge);
+    SLIME_CHECK_LAUNCH("merge_rows");
+    return SLIME_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile + normalise: uint8 HWC canvas -> planar normalised crops.  A workgroup handles one canvas
+// row segment of one crop: the 3*crop interleaved bytes are read coalesced, de-interleaved through
+// LDS, and each channel row is written coalesced.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* canvas, int Hc, int Wc, int crop,
+                                                             float3 mean, float3 sd, void* out, int out_dtype) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* line = reinterpret_cast<uint8_t*>(smem);
+    const int tiles_x = Wc / crop;
+    const int y = blockIdx.x % crop;
+    const int tile = blockIdx.x / crop;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint8_t* src = canvas + ((size_t)(ty * crop + y) * Wc + (size_t)tx * crop) * 3;
+    for (int i = threadIdx.x; i < crop * 3; i += blockDim.x) line[i] = src[i];
+    __syncthreads();
+    const float m[3] = {mean.x, mean.y, mean.z}, sdv[3] = {sd.x, sd.y, sd.z};
+    for (int i = threadIdx.x; i < crop * 3; i += blockDim.x) {
+        const int c = i / crop, x = i % crop;
+        // HF image_transforms: rescale = float32(float64(u8) * (1/255)); normalise = (x - mean) / std in fp32
+        const float v = ((float)((double)line[x * 3 + c] * (1.0 / 255.0)) - m[c]) / sdv[c];
+        const size_t o = (((size_t)tile * 3 + c) * crop + y) * crop + x;
+        if (out_dtype == SLIME_F32) reinterpret_cast<float*>(out)[o] = v;
+        else reinterpret_cast<unsigned short*>(out)[o] = to_t1<T>(v);
+    }
+}
+
+extern "C" int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3,
+                                    const float* std3, void* out, int out_dtype, void* stream) {
+    SLIME_REQUIRE(canvas && out && mean3 && std3, "tile_normalize: null pointer (mean3/std3 are HOST pointers)");
+    SLIME_REQUIRE(crop > 0 && Hc % crop == 0 && Wc % crop == 0, "tile_normalize: canvas %dx%d is not a multiple of %d", Hc, Wc, crop);
+    const int tiles = (Hc / crop) * (Wc / crop);
+    const float3 mean = make_float3(mean3[0], mean3[1], mean3[2]);
+    const float3 istd = make_float3(std3[0], std3[1], std3[2]);
+    const dim3 grid(tiles * crop), block(256);
+    const size_t lds = (size_t)crop * 3;
+    if (out_dtype == SLIME_F16) hipLaunchKernelGGL((tile_normalize_kernel<F16>), grid, block, lds, (hipStream_t)stream, canvas, Hc, Wc, crop, mean, istd, out, out_dtype);
+    else hipLaunchKernelGGL((tile_normalize_kernel<BF16>), grid, block, lds, (hipStream_t)stream, canvas, Hc, Wc, crop, mean, istd, out, out_dtype);
+    SLIME_CHECK_LAUNCH("tile_normalize");
+    return SLIME_OK;
+}

@@ -1,0 +1,385 @@
+"""Torch-tensor front end of libslime_hip: weight packing (load time) and thin call wrappers.
+
+PyTorch is plumbing here -- device memory, streams, dtype bookkeeping.  Every arithmetic step of the
+hot path runs in the HIP library; there is no eager / CPU fallback (``_lib.load()`` raises if the
+library is absent).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .weights import VisionConfig, AdapterConfig, strip_tower_prefix, sub_state
+
+_DT = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.F32, torch.uint8: _lib.U8}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {dt}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libslime_hip needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.SlimeHipError(f"{name} must live on the GPU: slime_amd has no CPU path")
+
+
+class Workspace:
+    """Grow-only scratch buffer (256-B aligned by the caching allocator's 512-B granularity)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+# ------------------------------------------------------------------------------------------------
+# primitive wrappers (used by the parity tests and by the modules)
+# ------------------------------------------------------------------------------------------------
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        odt = a.dtype if epilogue <= _lib.EPI_BIAS_GELU_T else torch.float32
+        out = torch.empty((M, N), dtype=odt, device=a.device)
+    _lib.check(lib.slime_gemm(_ptr(a), a.stride(0), _ptr(w), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
+                              dtype_code(a.dtype), epilogue, _stream()), "slime_gemm")
+    return out
+
+
+def layernorm(x: torch.Tensor, w, b, eps: float, dtype: torch.dtype, want_f32=False, want_t=True,
+              add: Optional[torch.Tensor] = None, normalize=True):
+    lib = _lib.load()
+    rows, D = x.shape
+    o32 = torch.empty((rows, D), dtype=torch.float32, device=x.device) if want_f32 else None
+    ot = torch.empty((rows, D), dtype=dtype, device=x.device) if want_t else None
+    ot2 = torch.empty((rows, D), dtype=dtype, device=x.device) if add is not None else None
+    _lib.check(lib.slime_layernorm(_ptr(x), x.stride(0), rows, D, _ptr(w), _ptr(b), float(eps), int(normalize),
+                                   _ptr(o32), _ptr(ot), _ptr(ot2), _ptr(add), add.shape[0] if add is not None else 0,
+                                   dtype_code(dtype), _stream()), "slime_layernorm")
+    return o32, ot, ot2
+
+
+def attention(q, k, v, heads: int, head_dim: int) -> torch.Tensor:
+    """q [B|1, nq, H*dh] (pre-scaled), k/v [B, nkv, H*dh] -> [B, nq, H*dh]; all T, last dim contiguous."""
+    lib = _lib.load()
+    B, nkv = k.shape[0], k.shape[1]
+    nq = q.shape[1]
+    o = torch.empty((B, nq, heads * head_dim), dtype=k.dtype, device=k.device)
+    for t in (q, k, v):
+        assert t.stride(-1) == 1
+    q_bs = 0 if q.shape[0] == 1 and B > 1 else q.stride(0)
+    _lib.check(lib.slime_attention(q.data_ptr(), q_bs, q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                   v.data_ptr(), v.stride(0), v.stride(1), o.data_ptr(), o.stride(0), o.stride(1),
+                                   B, heads, head_dim, nq, nkv, dtype_code(k.dtype), _stream()), "slime_attention")
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (load time; plain torch)
+# ------------------------------------------------------------------------------------------------
+
+@dataclass
+class PackedTower:
+    cfg: VisionConfig
+    dtype: torch.dtype
+    layers_run: int
+    tensors: Dict[str, torch.Tensor]
+    desc: _lib.VitDesc
+    ws: Workspace = field(default_factory=Workspace)
+
+    @property
+    def device(self):
+        return self.tensors["cls"].device
+
+
+def layers_for_select(cfg: VisionConfig, select_layer: int) -> int:
+    """hidden_states has L+1 entries; index i is produced by running i layers (clip_encoder.py:36-37)."""
+    L = cfg.num_hidden_layers
+    idx = select_layer if select_layer >= 0 else L + 1 + select_layer
+    if not 0 <= idx <= L:
+        raise ValueError(f"mm_vision_select_layer {select_layer} out of range for {L} layers")
+    return idx
+
+
+def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: torch.dtype, device,
+               select_layer: int = -2) -> PackedTower:
+    """HF CLIPVisionModel state dict (either key generation) -> device tensors in the kernels' layout."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("tower compute dtype must be bf16 or fp16 (MFMA operand type); fp32 I/O is supported")
+    sd = strip_tower_prefix(state_dict)
+    D, Fi, L = cfg.hidden_size, cfg.intermediate_size, layers_for_select(cfg, select_layer)
+    P2 = 3 * cfg.patch_size * cfg.patch_size
+    kpad = (P2 + 63) // 64 * 64
+    scale = cfg.head_dim ** -0.5
+
+    def f32(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def tt(t):
+        return t.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous()
+
+    pw = torch.zeros((D, kpad), dtype=torch.float32)
+    pw[:, :P2] = sd["embeddings.patch_embedding.weight"].detach().float().reshape(D, P2)
+    T: Dict[str, torch.Tensor] = {
+        "patch_w": tt(pw), "cls": f32(sd["embeddings.class_embedding"]),
+        "pos": f32(sd["embeddings.position_embedding.weight"]),
+        "pre_ln_w": f32(sd["pre_layrnorm.weight"]), "pre_ln_b": f32(sd["pre_layrnorm.bias"]),
+    }
+
+    def stack(fmt, conv, n=L):
+        if n == 0:
+            return None
+        return torch.stack([conv(sd[fmt.format(i)]) for i in range(n)]).contiguous()
+
+    if L > 0:
+        p = "encoder.layers.{}."
+        T["ln1_w"], T["ln1_b"] = stack(p + "layer_norm1.weight", f32), stack(p + "layer_norm1.bias", f32)
+        T["ln2_w"], T["ln2_b"] = stack(p + "layer_norm2.weight", f32), stack(p + "layer_norm2.bias", f32)
+        wq, bq = [], []
+        for i in range(L):
+            q = f"encoder.layers.{i}.self_attn."
+            wq.append(torch.cat([sd[q + "q_proj.weight"].float() * scale, sd[q + "k_proj.weight"].float(),
+                                 sd[q + "v_proj.weight"].float()], 0))
+            bq.append(torch.cat([sd[q + "q_proj.bias"].float() * scale, sd[q + "k_proj.bias"].float(),
+                                 sd[q + "v_proj.bias"].float()], 0))
+        T["w_qkv"] = torch.stack([tt(w) for w in wq]).contiguous()
+        T["b_qkv"] = torch.stack([f32(b) for b in bq]).contiguous()
+        T["w_o"], T["b_o"] = stack(p + "self_attn.out_proj.weight", tt), stack(p + "self_attn.out_proj.bias", f32)
+        T["w_fc1"], T["b_fc1"] = stack(p + "mlp.fc1.weight", tt), stack(p + "mlp.fc1.bias", f32)
+        T["w_fc2"], T["b_fc2"] = stack(p + "mlp.fc2.weight", tt), stack(p + "mlp.fc2.bias", f32)
+    d = _lib.VitDesc()
+    d.hidden, d.inter, d.heads, d.layers_run = D, Fi, cfg.num_attention_heads, L
+    d.image, d.patch, d.kpad, d.dtype, d.eps = cfg.image_size, cfg.patch_size, kpad, dtype_code(dtype), cfg.layer_norm_eps
+    for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o",
+                 "ln2_w", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+        setattr(d, name, T[name].data_ptr() if name in T and T[name] is not None else None)
+    return PackedTower(cfg, dtype, L, T, d)
+
+
+def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[torch.dtype] = None,
+                  keep_cls: bool = False, want_hidden: bool = False):
+    """pixels [N,3,S,S] (fp32 or the tower dtype) -> features [N, P(+1), D] in out_dtype."""
+    lib = _lib.load()
+    _require_cuda(pixels, "pixels")
+    cfg = pt.cfg
+    if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != cfg.image_size or pixels.shape[3] != cfg.image_size:
+        # HF raises on a size mismatch too (modeling_clip.py:204-207)
+        raise ValueError(f"Input image size ({tuple(pixels.shape[2:])}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
+    if pixels.dtype not in (torch.float32, pt.dtype):
+        pixels = pixels.to(pt.dtype)
+    pixels = pixels.contiguous()
+    n = pixels.shape[0]
+    out_dtype = out_dtype or pixels.dtype
+    rows = cfg.seq_len if keep_cls else cfg.num_patches
+    out = torch.empty((n, rows, cfg.hidden_size), dtype=out_dtype, device=pixels.device)
+    hidden = torch.empty((n, cfg.seq_len, cfg.hidden_size), dtype=torch.float32, device=pixels.device) if want_hidden else None
+    need = lib.slime_vit_workspace_bytes(C.byref(pt.desc), n)
+    ws = pt.ws.get(need, pixels.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_vit_forward(C.byref(pt.desc), pixels.data_ptr(), dtype_code(pixels.dtype), n, out.data_ptr(),
+                                     dtype_code(out_dtype), int(keep_cls), _ptr(hidden), base,
+                                     ws.numel() - (base - ws.data_ptr()), _stream()), "slime_vit_forward")
+    return (out, hidden) if want_hidden else out
+
+
+@dataclass
+class PackedResampler:
+    dim: int
+    heads: int
+    n_query: int
+    n_kv: int
+    dtype: torch.dtype
+    tensors: Dict[str, torch.Tensor]
+    desc: _lib.ResamplerDesc
+    ws: Workspace = field(default_factory=Workspace)
+
+
+def _abs_pos(table: torch.Tensor, side: int) -> torch.Tensor:
+    """get_abs_pos (sampler.py:27-36): bicubic resize of the square sincos table, rounded back to the
+    table's dtype (fp16 in the reference)."""
+    src = int(math.sqrt(table.shape[0]))
+    dt = table.dtype
+    return F.interpolate(table.float().reshape(1, src, src, -1).permute(0, 3, 1, 2), size=(side, side),
+                         mode="bicubic", align_corners=False).permute(0, 2, 3, 1).flatten(0, 2).to(dt)
+
+
+def pack_resampler(sd: Dict[str, torch.Tensor], dim: int, heads: int, n_kv: int, dtype: torch.dtype, device,
+                   eps: float = 1e-6) -> PackedResampler:
+    """Resampler state dict (keys as sampler.py:115-137) -> kernel layout.  The query side is input
+    independent (sampler.py:161-163) and is folded into ``q_proj`` here, in fp32, once."""
+    nq = sd["query"].shape[0]
+    dh = dim // heads
+    side = int(math.isqrt(n_kv))
+    assert side * side == n_kv, "key grid must be square (sampler.py:146-147)"
+    E = dim
+    in_w, in_b = sd["attn.in_proj_weight"].float().cpu(), sd["attn.in_proj_bias"].float().cpu()
+    pos_q = sd["pos_embed"].cpu()
+    q = F.layer_norm(sd["query"].float().cpu(), (E,), sd["ln_q.weight"].float().cpu(), sd["ln_q.bias"].float().cpu(), eps)
+    q = F.linear(q + pos_q.float(), in_w[:E], in_b[:E]) * dh ** -0.5
+    pos_k = _abs_pos(pos_q, side).float()
+
+    def f32(t):
+        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def tt(t):
+        return t.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous()
+
+    T = {"q_proj": tt(q), "pos_k": f32(pos_k), "ln_kv_w": f32(sd["ln_kv.weight"]), "ln_kv_b": f32(sd["ln_kv.bias"]),
+         "w_k": tt(in_w[E:2 * E]), "b_k": f32(in_b[E:2 * E]), "w_v": tt(in_w[2 * E:]), "b_v": f32(in_b[2 * E:]),
+         "w_o": tt(sd["attn.out_proj.weight"]), "b_o": f32(sd["attn.out_proj.bias"]),
+         "ln_post_w": f32(sd["ln_post.weight"]), "ln_post_b": f32(sd["ln_post.bias"])}
+    d = _lib.ResamplerDesc()
+    d.dim, d.heads, d.n_query, d.n_kv, d.dtype, d.eps = dim, heads, nq, n_kv, dtype_code(dtype), eps
+    for k, v in T.items():
+        setattr(d, k, v.data_ptr())
+    return PackedResampler(dim, heads, nq, n_kv, dtype, T, d)
+
+
+def resampler_forward(pr: PackedResampler, x: torch.Tensor, want_t: bool = False):
+    """x fp32 [n, n_kv, dim] -> fp32 [n, n_query, dim] (and the T copy if want_t)."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.float().contiguous()
+    n = x.shape[0]
+    assert x.shape[1] == pr.n_kv and x.shape[2] == pr.dim
+    out = torch.empty((n, pr.n_query, pr.dim), dtype=torch.float32, device=x.device)
+    out_t = torch.empty((n, pr.n_query, pr.dim), dtype=pr.dtype, device=x.device) if want_t else None
+    need = lib.slime_resampler_workspace_bytes(C.byref(pr.desc), n)
+    ws = pr.ws.get(need, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_resampler_forward(C.byref(pr.desc), x.data_ptr(), pr.dim, n, out.data_ptr(), _ptr(out_t), base,
+                                           ws.numel() - (base - ws.data_ptr()), _stream()), "slime_resampler_forward")
+    return (out, out_t) if want_t else out
+
+
+@dataclass
+class PackedMlp:
+    in_dim: int
+    hidden: int
+    dtype: torch.dtype
+    tensors: Dict[str, torch.Tensor]
+    desc: _lib.MlpDesc
+    ws: Workspace = field(default_factory=Workspace)
+
+
+def pack_mlp(w1, b1, w2, b2, dtype: torch.dtype, device) -> PackedMlp:
+    T = {"w1": w1.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous(),
+         "b1": b1.detach().to(device=device, dtype=torch.float32).contiguous(),
+         "w2": w2.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous(),
+         "b2": b2.detach().to(device=device, dtype=torch.float32).contiguous()}
+    d = _lib.MlpDesc()
+    d.in_dim, d.hidden, d.dtype = w1.shape[1], w1.shape[0], dtype_code(dtype)
+    for k, v in T.items():
+        setattr(d, k, v.data_ptr())
+    return PackedMlp(w1.shape[1], w1.shape[0], dtype, T, d)
+
+
+def mlp_forward(pm: PackedMlp, x: torch.Tensor) -> torch.Tensor:
+    """x [rows, in_dim] fp32 or T -> fp32 [rows, hidden]."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.contiguous()
+    rows = x.shape[0]
+    out = torch.empty((rows, pm.hidden), dtype=torch.float32, device=x.device)
+    need = lib.slime_mlp_workspace_bytes(C.byref(pm.desc), rows)
+    ws = pm.ws.get(need, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    xf = x.data_ptr() if x.dtype == torch.float32 else None
+    xt = x.data_ptr() if x.dtype == pm.dtype else None
+    if xf is None and xt is None:
+        x = x.float()
+        xf = x.data_ptr()
+    _lib.check(lib.slime_mlp_forward(C.byref(pm.desc), xf, xt, rows, out.data_ptr(), base,
+                                     ws.numel() - (base - ws.data_ptr()), _stream()), "slime_mlp_forward")
+    return out
+
+
+@dataclass
+class PackedGated:
+    mlp: PackedMlp
+    attn: PackedResampler
+    w_gate: torch.Tensor
+    ws: Workspace = field(default_factory=Workspace)
+
+
+def pack_gated(sd: Dict[str, torch.Tensor], cfg: AdapterConfig, dtype: torch.dtype, device) -> PackedGated:
+    """GatedBlock state dict (``mm_projector.`` prefix removed)."""
+    mlp = pack_mlp(sd["projection.0.weight"], sd["projection.0.bias"], sd["projection.2.weight"],
+                   sd["projection.2.bias"], dtype, device)
+    attn = pack_resampler(sub_state(sd, "attn."), cfg.mm_hidden_size, cfg.num_heads, cfg.global_queries, dtype,
+                          device, cfg.ln_eps)
+    # w_gate is a bf16 Parameter cast to the activation dtype at use (projector/builder.py:148)
+    wg = sd["w_gate"].detach().to(device=device, dtype=torch.float32).contiguous()
+    return PackedGated(mlp, attn, wg)
+
+
+def gated_forward(pg: PackedGated, x: torch.Tensor, learnable_gated: int = -1) -> torch.Tensor:
+    """x fp32 [n, 576, D] -> fp32 [n, 576, H]: the full GatedBlock path."""
+    lib = _lib.load()
+    _require_cuda(x, "x")
+    x = x.float().contiguous()
+    n, Tn, D = x.shape
+    assert Tn == pg.attn.n_kv and D == pg.mlp.in_dim
+    out = torch.empty((n, Tn, pg.mlp.hidden), dtype=torch.float32, device=x.device)
+    need = lib.slime_gated_workspace_bytes(C.byref(pg.mlp.desc), C.byref(pg.attn.desc), n)
+    ws = pg.ws.get(need, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_gated_forward(C.byref(pg.mlp.desc), C.byref(pg.attn.desc), pg.w_gate.data_ptr(),
+                                       int(learnable_gated), x.data_ptr(), n, out.data_ptr(), base,
+                                       ws.numel() - (base - ws.data_ptr()), _stream()), "slime_gated_forward")
+    return out
+
+
+def merge_rows(local: torch.Tensor, out: torch.Tensor, dst_row0: int, nw: int, nh: int, grid: int, merge: bool):
+    """Scatter [n, g*g, C] fp32 local tokens into ``out`` rows (spatial raster order or flat), casting."""
+    lib = _lib.load()
+    C_ = local.shape[-1]
+    _lib.check(lib.slime_merge_rows(_ptr(local), _ptr(out), dtype_code(out.dtype), int(dst_row0), nw, nh, grid, C_,
+                                    int(merge), _stream()), "slime_merge_rows")
+
+
+def gather_rows(src: torch.Tensor, out: torch.Tensor, rows_in: int, row_off: int, groups: int, rows_out: int):
+    lib = _lib.load()
+    _lib.check(lib.slime_gather_rows(_ptr(src), rows_in, row_off, _ptr(out), dtype_code(out.dtype), groups, rows_out,
+                                     src.shape[-1], _stream()), "slime_gather_rows")
+
+
+def tile_normalize(canvas_u8: torch.Tensor, crop: int, mean, std, out_dtype: torch.dtype) -> torch.Tensor:
+    """uint8 [Hc, Wc, 3] device canvas -> normalised crops [(Hc/crop)*(Wc/crop), 3, crop, crop]."""
+    lib = _lib.load()
+    _require_cuda(canvas_u8, "canvas")
+    Hc, Wc, _ = canvas_u8.shape
+    n = (Hc // crop) * (Wc // crop)
+    out = torch.empty((n, 3, crop, crop), dtype=out_dtype, device=canvas_u8.device)
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    _lib.check(lib.slime_tile_normalize(_ptr(canvas_u8.contiguous()), Hc, Wc, crop, m, s, out.data_ptr(),
+                                        dtype_code(out_dtype), _stream()), "slime_tile_normalize")
+    return out

@@ -1,0 +1,245 @@
+"""GPU parity tests of every HIP kernel behind the C ABI (run on the MI355X box: pytest -m gpu).
+
+Each kernel is compared with a plain fp32 torch restatement of the same op evaluated on the SAME
+16-bit-rounded operands, so the tolerances below bound only accumulation order (fp32 outputs) or one
+final 16-bit rounding (T outputs):
+    fp32 outputs : rel-L2 <= 2e-5
+    bf16 outputs : rel-L2 <= 4e-3   (bf16 unit roundoff 2^-9 = 1.95e-3 per element)
+    fp16 outputs : rel-L2 <= 6e-4   (fp16 unit roundoff 2^-12 = 4.9e-4)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_F32 = 2e-5
+TOL_T = {torch.bfloat16: 4e-3, torch.float16: 6e-4}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from slime_amd import _lib
+    _lib.load()                      # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (2, 1), (3, 1), (3, 0), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128)])
+def test_gemm_epilogues(dev, dtype, tile, sched, M, N, K):
+    from slime_amd import ops, _lib
+    lib = _lib.load()
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)     # asymmetric, random: catches row/col swaps
+    bias = _rand((N,), torch.float32, dev, 3)
+    ref = a.float() @ w.float().t() + bias
+    lib.slime_gemm_force_tile(tile)
+    lib.slime_gemm_set_sched(sched)
+    try:
+        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_F32)
+        assert rel_l2(out.cpu(), ref.cpu()) < TOL_F32
+        out = ops.gemm(a, w, None, _lib.EPI_BIAS_F32)
+        assert rel_l2(out.cpu(), (ref - bias).cpu()) < TOL_F32
+        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_T)
+        assert out.dtype == dtype and rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype]
+        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_QUICKGELU_T)
+        assert rel_l2(out.float().cpu(), (ref * torch.sigmoid(1.702 * ref)).cpu()) < TOL_T[dtype]
+        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_GELU_T)
+        assert rel_l2(out.float().cpu(), F.gelu(ref).cpu()) < TOL_T[dtype]
+        h = _rand((M, N), torch.float32, dev, 4)
+        h0 = h.clone()
+        ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h)
+        assert rel_l2(h.cpu(), (h0 + ref).cpu()) < TOL_F32
+    finally:
+        lib.slime_gemm_force_tile(0)
+        lib.slime_gemm_set_sched(1)
+
+
+def test_gemm_strided_and_identity(dev):
+    """lda/ldc > width (the q/k/v thirds of a packed buffer) and an A = I transpose check."""
+    from slime_amd import ops, _lib
+    dt = torch.bfloat16
+    big = _rand((500, 3 * 256), dt, dev, 5)
+    a = big[:, 256:512]                                   # lda = 768
+    w = _rand((384, 256), dt, dev, 6, 0.1)
+    outbuf = torch.zeros((500, 1024), dtype=torch.float32, device=dev)
+    out = outbuf[:, 128:512]                              # ldc = 1024
+    lib = _lib.load()
+    _lib.check(lib.slime_gemm(a.data_ptr(), a.stride(0), w.data_ptr(), None, out.data_ptr(), out.stride(0), 500, 384,
+                              256, _lib.BF16, _lib.EPI_BIAS_F32, torch.cuda.current_stream().cuda_stream))
+    assert rel_l2(out.cpu(), (a.float() @ w.float().t()).cpu()) < TOL_F32
+    assert float(outbuf[:, :128].abs().max()) == 0 and float(outbuf[:, 512:].abs().max()) == 0
+    eye = torch.eye(256, dtype=dt, device=dev)
+    out = ops.gemm(eye, w, None, _lib.EPI_BIAS_F32)       # I @ w.T == w.T exactly
+    assert torch.equal(out.cpu(), w.float().t().cpu())
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from slime_amd import ops, _lib
+    a = _rand((64, 96), torch.bfloat16, dev, 1)
+    w = _rand((128, 96), torch.bfloat16, dev, 2)
+    with pytest.raises(_lib.SlimeHipError, match="multiple of 64"):
+        ops.gemm(a, w, None, _lib.EPI_BIAS_F32)
+    a = _rand((64, 64), torch.bfloat16, dev, 1)
+    w = _rand((100, 64), torch.bfloat16, dev, 2)
+    with pytest.raises(_lib.SlimeHipError, match="multiple of 128"):
+        ops.gemm(a, w, None, _lib.EPI_BIAS_F32)
+
+
+# ------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("D", [128, 256, 1024])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm(dev, D, dtype):
+    from slime_amd import ops
+    rows = 577 * 2 + 3
+    x = _rand((rows, D), torch.float32, dev, 7, 3.0) + 0.7
+    w = _rand((D,), torch.float32, dev, 8) * 0.1 + 1
+    b = _rand((D,), torch.float32, dev, 9) * 0.1
+    add = _rand((577, D), torch.float32, dev, 10)
+    ref = F.layer_norm(x, (D,), w, b, 1e-5)
+    o32, ot, ot2 = ops.layernorm(x, w, b, 1e-5, dtype, want_f32=True, want_t=True, add=add)
+    assert rel_l2(o32.cpu(), ref.cpu()) < TOL_F32
+    assert rel_l2(ot.float().cpu(), ref.cpu()) < TOL_T[dtype]
+    idx = torch.arange(rows, device=dev) % 577
+    assert rel_l2(ot2.float().cpu(), (ref + add[idx]).cpu()) < TOL_T[dtype]
+    # cast-only mode
+    _, ot, _ = ops.layernorm(x, None, None, 0.0, dtype, normalize=False)
+    assert torch.equal(ot.cpu(), x.to(dtype).cpu())
+
+
+def test_im2col_and_embed(dev):
+    from slime_amd import _lib
+    lib = _lib.load()
+    n, image, patch, D = 2, 336, 14, 128
+    g = image // patch
+    px = _rand((n, 3, image, image), torch.float32, dev, 11)
+    kpad = 640
+    out = torch.empty((n * g * g, kpad), dtype=torch.bfloat16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.slime_im2col(px.data_ptr(), _lib.F32, out.data_ptr(), n, image, patch, kpad, _lib.BF16, st))
+    ref = F.unfold(px, kernel_size=patch, stride=patch).transpose(1, 2).reshape(n * g * g, 588)   # (c,ky,kx) order
+    assert torch.equal(out[:, :588].cpu(), ref.to(torch.bfloat16).cpu())
+    assert float(out[:, 588:].float().abs().max()) == 0
+    # 16-bit pixels path
+    pxh = px.to(torch.bfloat16)
+    out2 = torch.empty_like(out)
+    _lib.check(lib.slime_im2col(pxh.data_ptr(), _lib.BF16, out2.data_ptr(), n, image, patch, kpad, _lib.BF16, st))
+    assert torch.equal(out2.cpu(), out.cpu())
+    # embed + pre-LN
+    P = g * g
+    pe = _rand((n * P, D), torch.float32, dev, 12)
+    cls = _rand((D,), torch.float32, dev, 13)
+    pos = _rand((P + 1, D), torch.float32, dev, 14)
+    w = _rand((D,), torch.float32, dev, 15) * 0.1 + 1
+    b = _rand((D,), torch.float32, dev, 16) * 0.1
+    h = torch.empty((n, P + 1, D), dtype=torch.float32, device=dev)
+    _lib.check(lib.slime_embed_prenorm(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5,
+                                       h.data_ptr(), n, P, D, st))
+    x = torch.cat([cls.expand(n, 1, D), pe.view(n, P, D)], 1) + pos
+    assert rel_l2(h.cpu(), F.layer_norm(x, (D,), w, b, 1e-5).cpu()) < TOL_F32
+
+
+def test_gate_mix_gather_merge(dev):
+    from slime_amd import ops, _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    rows, D, H = 576, 128, 256
+    x = _rand((rows, D), torch.float32, dev, 17)
+    wg = _rand((D, 2), torch.float32, dev, 18, 0.2)
+    e0 = _rand((rows, H), torch.float32, dev, 19)
+    e1 = _rand((rows, H), torch.float32, dev, 20)
+    out = torch.empty_like(e0)
+    _lib.check(lib.slime_gate_mix(x.data_ptr(), D, wg.data_ptr(), e0.data_ptr(), e1.data_ptr(), out.data_ptr(), rows, H, st))
+    p = torch.softmax(x @ wg, 1)
+    gts = p / (p.sum(1, keepdim=True) + 1e-6)
+    assert rel_l2(out.cpu(), (e0 * gts[:, :1] + e1 * gts[:, 1:]).cpu()) < TOL_F32
+    # gather: drop the class token, cast
+    h = _rand((3, 577, D), torch.float32, dev, 21)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        o = torch.empty((3, 576, D), dtype=dt, device=dev)
+        ops.gather_rows(h, o, 577, 1, 3, 576)
+        assert torch.equal(o.cpu(), h[:, 1:].to(dt).cpu())
+    # spatial merge (llava_arch.py:235-244) for a 2 x 3 grid of 12 x 12 tokens
+    nw, nh, g = 2, 3, 12
+    loc = _rand((nw * nh, g * g, H), torch.float32, dev, 22)
+    o = torch.zeros((5 + nw * nh * g * g, H), dtype=torch.float32, device=dev)
+    ops.merge_rows(loc, o, 5, nw, nh, g, True)
+    ref = loc.view(nh, nw, g, g, H).permute(0, 2, 1, 3, 4).reshape(-1, H)
+    assert torch.equal(o[5:].cpu(), ref.cpu()) and float(o[:5].abs().max()) == 0
+    ops.merge_rows(loc, o, 5, nw, nh, g, False)
+    assert torch.equal(o[5:].cpu(), loc.view(-1, H).cpu())
+
+
+def test_tile_normalize(dev):
+    from slime_amd import ops
+    g = torch.Generator().manual_seed(23)
+    canvas = torch.randint(0, 256, (672, 1008, 3), generator=g, dtype=torch.uint8)
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    out = ops.tile_normalize(canvas.to(dev), 336, mean, std, torch.float32)
+    x = canvas.float() * (1.0 / 255.0)
+    x = (x - torch.tensor(mean)) / torch.tensor(std)
+    ref = x.view(2, 336, 3, 336, 3).permute(0, 2, 4, 1, 3).reshape(6, 3, 336, 336)
+    assert float((out.cpu() - ref).abs().max()) < 2e-6
+    outh = ops.tile_normalize(canvas.to(dev), 336, mean, std, torch.bfloat16)
+    assert rel_l2(outh.float().cpu(), ref) < TOL_T[torch.bfloat16]
+
+
+# -------------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, heads, dh):
+    B, nq = k.shape[0], q.shape[1]
+    qf = q.float().expand(B, -1, -1).reshape(B, nq, heads, dh).transpose(1, 2)
+    kf = k.float().reshape(B, -1, heads, dh).transpose(1, 2)
+    vf = v.float().reshape(B, -1, heads, dh).transpose(1, 2)
+    att = torch.softmax(qf @ kf.transpose(-1, -2), -1)      # q already carries the scale
+    return (att @ vf).transpose(1, 2).reshape(B, nq, heads * dh)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,heads,dh,nq,nkv,shared_q", [
+    (3, 2, 64, 577, 577, False),     # CLIP self-attention geometry (ragged: 577 = 18*32 + 1)
+    (2, 16, 64, 577, 577, False),    # 16 heads
+    (1, 1, 64, 40, 100, False),      # short, ragged kv
+    (2, 2, 64, 700, 1300, False),    # kv longer than one LDS chunk (608)
+    (4, 2, 128, 144, 576, True),     # post_qformer: 144 shared queries x 576 keys
+    (2, 8, 128, 576, 576, True),     # GatedBlock.attn: 576 queries (q-split over two workgroups)
+    (1, 1, 128, 33, 64, False),
+])
+def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
+    from slime_amd import ops
+    E = heads * dh
+    q = _rand((1 if shared_q else B, nq, E), dtype, dev, 30, dh ** -0.5)
+    k = _rand((B, nkv, E), dtype, dev, 31)
+    v = _rand((B, nkv, E), dtype, dev, 32)
+    out = ops.attention(q, k, v, heads, dh)
+    ref = _attn_ref(q, k, v, heads, dh)
+    assert rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype] * 1.5   # + P rounded to T before PV
+
+
+def test_attention_packed_qkv_and_spike(dev):
+    """q/k/v as thirds of one packed [B,S,3E] buffer (the tower's layout), and a forced running-max
+    jump: one key row spiked against one query so the online-softmax rescale branch is exercised
+    late in the kv sweep (cdna guide rule 26)."""
+    from slime_amd import ops
+    B, S, heads, dh = 2, 577, 2, 64
+    E = heads * dh
+    qkv = _rand((B, S, 3 * E), torch.bfloat16, dev, 33)
+    qkv[..., :E] *= dh ** -0.5
+    qkv[0, 500, E:2 * E] = qkv[0, 17, :E] * 60.0            # k[500] aligned with q[17]: huge logit at kv=500
+    q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
+    out = ops.attention(q, k, v, heads, dh)
+    ref = _attn_ref(q, k, v, heads, dh)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
+    assert rel_l2(out[0, 17].float().cpu(), ref[0, 17].cpu()) < 6e-3
