@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Contract benchmark: image-crops/sec of the SliME visual hot path (ViT + projector) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = one pass of the hot path over one batch of synthetic input of BASELINE.json configs[1]:
+8 images x (1 global + 4 local) 336x336 crops = 40 crops per GPU (weak scaling: the global batch is
+8*N images), bf16 MFMA operands, inputs already resident in HBM:
+
+    CLIP-ViT-L/14-336 tower over all crops of the rank (23 live layers)  ->  [N>1] RCCL all-gather of the
+    bf16 tower features of all ranks  ->  gated global adapter (576 tokens/image), post_qformer local
+    compression (144 tokens/crop) + MLP projector, spatial merge into LLM-ready token rows.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (the fused-epilogue MFMA GEMM; the heaviest launch shape of the
+                 step), algorithmic FLOPs / live HIP-event duration, against the dense bf16 MFMA peak;
+  cpu_baseline : the CPU oracle (oracle/slime_oracle.py, a restatement validated against the
+                 reference) timed on this box's host cores on a bounded sample (N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMAGES_PER_GPU = 8
+LOCAL_CROPS = 4                        # 672x672 input -> 2x2 local grid
+CROPS_PER_IMAGE = 1 + LOCAL_CROPS
+GF_VIT_PER_CROP = 366.034              # live ViT path, 23 layers, S = 577
+GF_GLOBAL_PER_IMAGE = 54.512           # gated adapter on the global view
+GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
+PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters=10, warm=2):
+    """Average duration of ``fn`` (one kernel launch) with HIP events on the launching stream."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def kernel_roofline(dev, crops_per_launch):
+    """Time the four GEMM launch shapes of one tower layer (M = crops*577) and report the dominant."""
+    from slime_amd import ops, _lib
+    dt = torch.bfloat16
+    M = crops_per_launch * 577
+    shapes = {"qkv_proj": (3072, 1024, _lib.EPI_BIAS_T), "out_proj+residual": (1024, 1024, _lib.EPI_BIAS_RESID_F32),
+              "fc1+quick_gelu": (4096, 1024, _lib.EPI_BIAS_QUICKGELU_T), "fc2+residual": (1024, 4096, _lib.EPI_BIAS_RESID_F32)}
+    per = {}
+    for name, (N, K, epi) in shapes.items():
+        a = torch.randn(M, K, device=dev).to(dt)
+        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
+        b = torch.randn(N, device=dev)
+        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi >= _lib.EPI_BIAS_F32 else dt)
+        ms = event_time_ms(lambda: ops.gemm(a, w, b, epi, out=out))
+        fl = 2.0 * M * N * K
+        per[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "M": M, "N": N, "K": K}
+        del a, w, b, out
+    dom = max(per, key=lambda k: per[k]["ms"])
+    return dom, per
+
+
+def cpu_baseline(tower_sd, adapter_sd):
+    """Oracle (CPU restatement of the reference) on one 1+4 image; a reported baseline, not a target."""
+    from oracle import slime_oracle as O
+    from slime_amd import weights as W
+    px = W.synthetic_pixels(CROPS_PER_IMAGE, seed=7)
+    tsd = W.strip_tower_prefix(tower_sd)
+    best = None
+    t_all = time.perf_counter()
+    for _ in range(2):
+        t0 = time.perf_counter()
+        O.encode_image(tsd, adapter_sd, W.CLIP_L_336, W.ADAPTER_8B, px, (672, 672))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        if time.perf_counter() - t_all > 20:
+            break
+    return {"value": round(CROPS_PER_IMAGE / best, 3), "unit": "crops/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"1 image x (1+4) crops, fp32 torch CPU oracle (tower 23 layers + adapter + merge), best of <=2 runs, {best:.2f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from slime_amd import weights as W, ops
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
+    from slime_amd.dist import sharded_tower_gather
+
+    dt = torch.bfloat16
+    tower_sd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)
+    adapter_sd = W.make_adapter_state_dict(W.ADAPTER_8B, seed=4321)
+    enc = SlimeVisualEncoder(default_slime_config("synthetic:1234"))
+    enc.load_visual_state(tower_sd, adapter_sd)
+    enc.to(dev)
+    enc.get_vision_tower().vision_tower.to(dt)          # bf16 tower (training dtype of the reference, BASELINE cfg)
+    model = enc.get_model()
+    tower = enc.get_vision_tower()
+
+    n_local = IMAGES_PER_GPU * CROPS_PER_IMAGE
+    pixels = W.synthetic_pixels(n_local, seed=100 + rank).to(dev).to(dt)     # resident in HBM before timing
+    split_sizes = [CROPS_PER_IMAGE] * IMAGES_PER_GPU
+    image_sizes = [(672, 672)] * IMAGES_PER_GPU
+    g = model.sampler.grid_size
+    rows_per_image = 576 + LOCAL_CROPS * g * g
+    from slime_amd.model.llava_arch import _split_indices
+    g_idx, l_idx = _split_indices(split_sizes, dev)
+
+    def step():
+        feats = tower(pixels)                                                # [40,576,1024] bf16
+        if world > 1:
+            allf = sharded_tower_gather(feats, world)                        # [40*G,576,1024] on every rank
+            feats = allf[rank * n_local:(rank + 1) * n_local]
+        glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)
+        comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)
+        loc = model.mm_projector(comp, out_dtype=torch.float32)
+        tokens = torch.empty((IMAGES_PER_GPU, rows_per_image, glob.shape[-1]), dtype=dt, device=dev)
+        for i in range(IMAGES_PER_GPU):
+            ti = tokens[i]
+            ops.merge_rows(glob[i:i + 1].contiguous(), ti, 0, 1, 1, 24, False)              # global rows, cast
+            ops.merge_rows(loc[i * LOCAL_CROPS:(i + 1) * LOCAL_CROPS].contiguous(), ti, 576, 2, 2, g, True)
+        return tokens
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert torch.isfinite(out.float()).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        crops_total = n_local * world * args.steps
+        value = crops_total / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        step_gf = n_local * GF_VIT_PER_CROP + IMAGES_PER_GPU * GF_GLOBAL_PER_IMAGE + IMAGES_PER_GPU * LOCAL_CROPS * GF_LOCAL_PER_CROP
+        path_tflops = step_gf * world / (elapsed / args.steps) / 1e3
+        halves = 2 if tower.vision_tower.two_streams else 1
+        dom, per = kernel_roofline(dev, n_local // halves)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.isfile(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("dominant_gemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid",
+            "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), "
+                                   "tower + gated adapter + post_qformer + MLP projector + spatial merge",
+                       "crops_per_gpu": n_local, "images_per_gpu": IMAGES_PER_GPU, "grid": "1+4",
+                       "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),
+                       "tower_streams": halves},
+            "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
+                          "gflop_per_step_per_gpu": round(step_gf, 1)},
+            "roofline": {"bound": "mfma", "kernel": f"gemm_pp_kernel<bf16> ({dom}, M={per[dom]['M']} N={per[dom]['N']} K={per[dom]['K']})",
+                         "achieved": per[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(per[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "launch_ms": per[dom]["ms"], "all_gemm_shapes": per},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,19 @@ int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, i
 int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3_host,
                          const float* std3_host, void* out, int out_dtype, void* stream);
 
+/* Text-guided router, scores (TextGuidedRouterCosine.forward, resampler/builder.py:186-201):
+ * scores[t] = sum_l mask[l] * cos(img[t], text[l]) (mean over l if mask is NULL); img fp32 [T,H], text fp32
+ * [L,H], mask uint8 [L]; ws: L+H+4 floats of scratch. */
+int slime_router_scores(const float* img, int T, const float* text, int L, const unsigned char* mask, int H,
+                        float* scores, float* ws, void* stream);
+
+/* Top-p selection (TextGuidedSampler.forward eval path, resampler/builder.py:258-272): softmax(scores/temp),
+ * sort descending, keep the prefix whose cumulative sum is <= topp plus one more token; writes the kept
+ * token indices in ascending order to keep_idx[0..*keep_count) (device). probs_out (optional) gets the
+ * softmax.  T <= 4096. */
+int slime_router_select(const float* scores, int T, float temp, float topp, int* keep_idx, int* keep_count,
+                        float* probs_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CLIP vision tower (CLIPVisionTower.forward + feature_select, clip_encoder.py:36-58)
  * ---------------------------------------------------------------------------------------------- */

@@ -212,6 +212,212 @@ gemm_kernel(GemmArgs g) {
     }
 }
 
+
+// ================================================================================================
+// Ping-pong kernel (256 x 256 x 64 tile, 8 waves = two groups of 4, one group per A half).
+//
+// Every K-tile is cut in 4 phases (the four 64 x 32 quadrants of a wave's 128 x 64 output); a phase
+// is an L section (ds_read the quadrant's fragments + issue 2 LDS-DMA pieces) and an M section
+// (16 MFMAs), each closed by a workgroup barrier.  Group 1 runs ONE barrier behind group 0, so in
+// every barrier-to-barrier slot one group is in an M section while the other is in an L section:
+// each SIMD hosts one wave of either group, hence its matrix pipe always has a wave issuing MFMAs
+// while the partner wave hides LDS latency, DMA issue and barrier skew.
+//
+// LDS-DMA schedule (slot = barrier interval; tile t phase p: group 0 L at 8t+2p, M at 8t+2p+1; group
+// 1 one slot later).  A stage buffer is reused for tile t+2 region by region as soon as its last
+// reader is done; a group refills its own A quarters and half of either B half:
+//     section   group 0 issues             group 1 issues            (first reader)
+//     L1(t)     A rows   0..63  of t+2     A rows 128..191 of t+2    L0(t+2)
+//     L2(t)     B half 0, part 0 of t+2    B half 0, part 1 of t+2   L0(t+2)
+//     L3(t)     B half 1, part 0 of t+2    B half 1, part 1 of t+2   L1(t+2)
+//     L0(t+1)   A rows  64..127 of t+2     A rows 192..255 of t+2    L2(t+2)
+// Every piece is issued >= 2 slots after the last ds_read of the bytes it overwrites has been
+// waited for (lgkmcnt(0) opens each M section), and it is retired by its issuing wave exactly 4 of
+// its own sections later with a COUNTED s_waitcnt vmcnt(8) (2 pieces issued per section, 8 stay
+// in flight => >= 12 slots of flight), one barrier or more before its first reader.  The main
+// loop never drains vmcnt to 0 until no further tile exists.
+// ================================================================================================
+#define PP_BARRIER()                                   \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("s_barrier" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+
+template <typename T, int EPI>
+__global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int GROUP_M = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int group_id = pid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % in_group) % gsz;
+    const int tn = (pid % in_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;            // group == A half (wm)
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- LDS-DMA pieces owned by this wave: kind 0 = A quarter (rows 0..63 of the group's half),
+    // kind 1 = B half 0 part, kind 2 = B half 1 part, kind 3 = A quarter (rows 64..127); 2 pieces each.
+    const char* src[4][2];
+    int dst[4][2];                                       // byte offset inside a stage
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wn * 2 + j;                    // 0..7 inside the group's share
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa) {                 // A quarters
+            const int row = grp * 128 + qa * 64 + piece * 8;
+            const int gm = min(m0 + row + lrow, g.M - 1);
+            src[qa ? 3 : 0][j] = g.A + ((size_t)gm * g.lda) * 2 + lchunk * 16;
+            dst[qa ? 3 : 0][j] = row * 128;
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                 // B halves: LDS rows chunk*64 + hb*32 + sub*8
+            const int chunk = grp * 2 + (piece >> 2), sub = piece & 3;
+            const int rho = chunk * 64 + hb * 32 + sub * 8 + lrow;
+            const int nl = rho & 15;
+            const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
+            src[1 + hb][j] = g.B + ((size_t)(n0 + nphys) * g.K) * 2 + lchunk * 16;
+            dst[1 + hb][j] = A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
+        }
+    }
+    auto issue = [&](int kind, int tile) {               // 2 pieces of `kind` for k-tile `tile`
+        char* base = smem + (tile & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src[kind][j]), LDS_PTR(base + dst[kind][j]), 16, 0, 0);
+            src[kind][j] += BK * 2;
+        }
+    };
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sw = ((ks * 4 + lq) ^ (lane & 7)) << 4;
+        a_off[ks] = (grp * 128 + li) * 128 + sw;
+        b_off[ks] = A_BYTES + (wn * 64 + li) * 128 + sw;
+    }
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    // ---- prologue: all of tile 0, and the tile-1 pieces that "earlier" sections would have issued
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    if (nk > 1) {
+        issue(0, 1); issue(1, 1); issue(2, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();                          // group 1 runs one slot behind
+
+    u32x4 af[4][2], bf[2][2][2];
+    for (int t = 0; t < nk; ++t) {
+        const char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int mh = (p >> 1), nh = (p == 1 || p == 2) ? 1 : 0;   // (0,0) (0,1) (1,1) (1,0)
+            // ---------------- L section ----------------
+            if (p == 0) {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        bf[0][nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + (nj * 16) * 128);
+            }
+            if (p == 0 || p == 2) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (mh * 64 + mi * 16) * 128);
+            }
+            if (p == 1) {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        bf[1][nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + (32 + nj * 16) * 128);
+            }
+            {
+                const int kind = (p == 0) ? 3 : p - 1;    // L0: A rows 64..127 (tile t+1); L1..L3: tile t+2
+                const int itile = (p == 0) ? t + 1 : t + 2;
+                if (itile < nk) {
+                    issue(kind, itile);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            PP_BARRIER();
+            // ---------------- M section ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        acc[mh * 4 + mi][nh * 2 + nj] = T::mfma16(bf[nh][nj][ks], af[mi][ks], acc[mh * 4 + mi][nh * 2 + nj]);
+            __builtin_amdgcn_s_setprio(0);
+            PP_BARRIER();
+        }
+    }
+    if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
+
+    const int q = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = m0 + grp * 128 + i * 16 + (lane & 15);
+        if (row < g.M) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int col = n0 + wn * 64 + 32 * p + 8 * q;
+                float v[8] = {acc[i][2 * p][0], acc[i][2 * p][1], acc[i][2 * p][2], acc[i][2 * p][3],
+                              acc[i][2 * p + 1][0], acc[i][2 * p + 1][1], acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]};
+                epilogue_store<T, EPI>(g, row, col, v);
+            }
+        }
+    }
+}
+
+template <typename T, int EPI>
+static int launch_pp(const GemmArgs& g, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 + 256) * 64 * 2;
+    auto kern = gemm_pp_kernel<T, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
+    SLIME_CHECK_LAUNCH("gemm_pp");
+    return SLIME_OK;
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * 64 * 2;
@@ -230,10 +436,11 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     return SLIME_OK;
 }
 
-// Tile choice.  256x256 (8 waves, 128 KiB LDS, 1 WG/CU) is the throughput tile; 256x128 is used
-// when it fills the last round of CUs better (N = 1024 GEMMs at M ~ 23k: 728 vs 364 workgroups);
-// 128x128 (4 waves, 64 KiB) covers narrow N (tiny geometries) and small M.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256, 2 = 256x128, 3 = 128x128
+// Tile choice.  The 256x256 ping-pong kernel is the throughput kernel (measured equal or better than
+// the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
+// covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
+// running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
+static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256, 2 = 256x128, 3 = 128x128, 4 = 256x256 ping-pong
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
@@ -241,17 +448,9 @@ extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
-    if (tile == 0) {
-        if (g.N % 256 == 0 && g.M >= 1024) {
-            const long b256 = (long)((g.M + 255) / 256) * (g.N / 256);
-            const long b128 = b256 * 2;
-            auto eff = [](long b) { long r = (b + 255) / 256; return (double)b / (double)(r * 256); };
-            tile = (eff(b128) > eff(b256) + 0.12) ? 2 : 1;
-        } else {
-            tile = 3;
-        }
-    }
-    if (tile == 1 && g.N % 256 != 0) tile = 3;
+    if (tile == 0) tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;   // ping-pong 256x256, else 128x128
+    if ((tile == 1 || tile == 4) && g.N % 256 != 0) tile = 3;
+    if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (g_sched == 0) {
         switch (tile) {
             case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream);

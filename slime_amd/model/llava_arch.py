@@ -1,0 +1,253 @@
+"""Multimodal glue for the visual hot path: the build's counterpart of ``LlavaMetaModel`` /
+``LlavaMetaForCausalLM.encode_images`` (llava/model/llava_arch.py:28-44,212-269).
+
+Same plugin construction (three builders driven by the same config attribute names), same stage
+order and outputs as the reference's ``encode_images`` sampler branch:
+
+    tower(all crops) -> global = mm_projector(crop 0) ; local = mm_projector(post_qformer(crops 1..n))
+    -> drop masked crops -> merge ('spatial' raster / 'flat') -> text-guided router -> cat(global, sep, local)
+
+but scheduled for the GPU instead of per image: the reference loops over images in Python and calls the
+ViT once per image (llava_arch.py:222); here ALL crops of the batch go through the tower as one batch,
+all global views through one GatedBlock launch sequence and all local crops through one
+post_qformer + MLP sequence; only the tiny data-dependent tail (merge, router, concat) is per image.
+The tower hands fp32 features to the adapter (the reference hands over fp16/bf16).
+
+``SlimeMetaForCausalLM`` can be mixed into an HF causal LM exactly like ``LlavaMetaForCausalLM``
+(INTEGRATION.md); ``SlimeVisualEncoder`` is the standalone form used by bench.py and the tests.
+"""
+from __future__ import annotations
+
+import math
+from abc import ABC, abstractmethod
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .multimodal_encoder.builder import build_vision_tower
+from .multimodal_projector.builder import build_vision_projector, GatedBlock
+from .multimodal_resampler.builder import build_vision_sampler
+from .. import ops
+from ..constants import IMAGE_TOKEN_INDEX
+from ..mm_utils import get_anyres_image_grid_shape
+
+
+def _split_indices(split_sizes, device):
+    """Row indices of the global views (crop 0 of every image) and of the local crops in the flat crop
+    batch (host-side index math, no device sync)."""
+    g, l, off = [], [], 0
+    for s in split_sizes:
+        g.append(off)
+        l.extend(range(off + 1, off + s))
+        off += s
+    return (torch.tensor(g, dtype=torch.long, device=device), torch.tensor(l, dtype=torch.long, device=device))
+
+
+class SlimeMetaModel:
+    """Mixin: builds the three hot-path plugins from the config (llava_arch.py:28-44)."""
+
+    def __init__(self, config):
+        super(SlimeMetaModel, self).__init__(config)
+        if hasattr(config, "mm_vision_tower"):
+            self.vision_tower = build_vision_tower(config, delay_load=True)
+            self.mm_projector = build_vision_projector(config)
+            self.sampler = build_vision_sampler(config)
+            t = getattr(config, "mm_resampler_type", None)
+            self.has_sampler = t != "identity" and t is not None and t != "spatial"
+
+    def get_vision_tower(self):
+        vt = getattr(self, "vision_tower", None)
+        return vt[0] if type(vt) is list else vt
+
+
+class SlimeMetaForCausalLM(ABC):
+    @abstractmethod
+    def get_model(self):
+        ...
+
+    def get_vision_tower(self):
+        return self.get_model().get_vision_tower()
+
+    # ------------------------------------------------------------------ text side (router input)
+    def get_pure_text_embedding(self, input_ids, attention_mask=None, labels=None):
+        """Embeddings of the text tokens with the <image> placeholders removed, zero rows appended
+        (or prepended for left padding) in their place (llava_arch.py:162-210)."""
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        embed = self.get_model().embed_tokens
+        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"
+        embs, masks = [], []
+        for ids, am in zip(input_ids, attention_mask):
+            keep = ids != IMAGE_TOKEN_INDEX
+            n_img = int((~keep).sum())
+            e, m = embed(ids[keep]), am[keep]
+            if n_img > 0:
+                ze = torch.zeros((n_img, e.shape[1]), dtype=e.dtype, device=e.device)
+                zm = torch.zeros((n_img,), dtype=m.dtype, device=m.device)
+                e, m = (torch.cat((ze, e)), torch.cat((zm, m))) if left else (torch.cat((e, ze)), torch.cat((m, zm)))
+            embs.append(e)
+            masks.append(m)
+        max_len = getattr(self.config, "tokenizer_model_max_length", None)
+        if max_len is not None:
+            embs, masks = [x[:max_len] for x in embs], [x[:max_len] for x in masks]
+        embs, masks = torch.stack(embs, 0), torch.stack(masks, 0)
+        assert masks.shape == embs.shape[:2]
+        return embs, masks
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.no_grad()
+    def encode_images(self, images, input_ids=None, split_sizes=None, attention_mask=None, images_mask=None,
+                      image_sizes=None, labels=None):
+        model = self.get_model()
+        tower = model.get_vision_tower()
+        cfg = self.config
+        merge_type = getattr(cfg, "mm_patch_merge_type", "flat")
+        use_local_only = getattr(cfg, "use_local_only", False)
+        use_global_only = getattr(cfg, "use_global_only", False)
+        out_dtype = images.dtype
+
+        if model.has_sampler and split_sizes is not None:
+            sep = model.embed_tokens(torch.tensor(cfg.seperator, dtype=input_ids.dtype, device=input_ids.device))
+            text_emb, text_mask = self.get_pure_text_embedding(input_ids, attention_mask, labels)
+            feats = tower(images, out_dtype=torch.float32)                      # [sum(1+n_i), 576, D], one batch
+            B = len(split_sizes)
+            dev = feats.device
+            g_idx, l_idx = _split_indices(split_sizes, dev)
+            glob = loc = None
+            if not use_local_only:
+                glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)             # [B,576,H]
+            if not use_global_only:
+                comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)    # [sum n_i,144,D]
+                loc = model.mm_projector(comp, out_dtype=torch.float32)                          # [sum n_i,144,H]
+            g = model.sampler.grid_size
+            outs = []
+            lstart = 0
+            for i in range(B):
+                n_i = split_sizes[i] - 1
+                pieces = []
+                if glob is not None:
+                    pieces.append(glob[i])
+                if loc is not None:
+                    li = loc[lstart:lstart + n_i]
+                    lstart += n_i
+                    if images_mask is not None and images_mask[0].size(0) - 1 == li.size(0):
+                        li = li[torch.nonzero(images_mask[i][1:]).squeeze(1)]    # padded crops (train.py:903-926)
+                    H = li.shape[-1]
+                    merged = torch.empty((li.shape[0] * g * g, H), dtype=torch.float32, device=dev)
+                    if li.shape[0] > 0:
+                        if merge_type == "spatial":
+                            nw, nh = get_anyres_image_grid_shape(image_sizes[i], cfg.image_grid_pinpoints,
+                                                                 tower.config.image_size)
+                            if nw * nh != li.shape[0]:
+                                raise ValueError(f"image {i}: grid {nw}x{nh} does not match {li.shape[0]} local crops")
+                            ops.merge_rows(li.contiguous(), merged, 0, nw, nh, g, True)
+                        elif merge_type == "flat":
+                            ops.merge_rows(li.contiguous(), merged, 0, li.shape[0], 1, g, False)
+                        else:
+                            raise NotImplementedError(f"mm_patch_merge_type={merge_type!r}")
+                    merged = model.sampler(merged, text_embedding=text_emb[i], attn_mask=text_mask[i])
+                    if glob is not None:
+                        pieces.append(sep.to(device=dev, dtype=torch.float32).unsqueeze(0))
+                    pieces.append(merged)
+                outs.append(torch.cat(pieces, dim=0).to(out_dtype).unsqueeze(0))
+            return outs, split_sizes
+
+        if split_sizes is not None:                                               # no sampler: per-image lists
+            feats = tower(images, out_dtype=torch.float32)
+            proj = model.mm_projector(feats, out_dtype=out_dtype) if not isinstance(model.mm_projector, GatedBlock) \
+                else torch.cat([model.mm_projector(f, out_dtype=out_dtype) for f in torch.split(feats, 1)], 0)
+            return list(torch.split(proj, split_sizes, dim=0)), split_sizes
+
+        feats = tower(images, out_dtype=torch.float32)
+        return model.mm_projector(feats, out_dtype=out_dtype), split_sizes
+
+
+class _Cfg:
+    """Attribute bag with the config names the reference persists (llava_arch.py:64-93)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def default_slime_config(vision_tower: str = "synthetic:1234", hidden_size: int = 4096, mm_hidden_size: int = 1024,
+                         **over) -> _Cfg:
+    """SliME-8B inference configuration (scripts/llama/llama3_8b_sft.sh:14-48)."""
+    d = dict(mm_vision_tower=vision_tower, mm_vision_select_layer=-2, mm_vision_select_feature="patch",
+             mm_projector_type="gated", mm_hidden_size=mm_hidden_size, hidden_size=hidden_size,
+             mm_patch_merge_type="spatial", image_aspect_ratio="anyres", mm_resampler_type="cosine",
+             mm_resampler_topp=0.95, mm_resampler_dim=144, mm_resampler_temp=1.0, mm_learnable_gated=-1,
+             image_grid_pinpoints="[(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]",
+             seperator=1919, pad_token_id=0, use_local_only=False, use_global_only=False)
+    d.update(over)
+    return _Cfg(**d)
+
+
+class _ModelBase(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+
+class _VisualModel(SlimeMetaModel, _ModelBase):
+    def __init__(self, config, embed_tokens: Optional[nn.Module] = None):
+        super().__init__(config)
+        self.embed_tokens = embed_tokens
+
+
+class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
+    """Standalone visual front end: tower + adapter + glue, no LLM.  ``embed_tokens`` (the LLM's
+    embedding table) is only needed for the separator token and the text-guided router."""
+
+    def __init__(self, config, embed_tokens: Optional[nn.Module] = None):
+        super().__init__()
+        self.config = config
+        self.model = _VisualModel(config, embed_tokens)
+
+    def get_model(self):
+        return self.model
+
+    def load_visual_state(self, tower_sd=None, adapter_sd=None):
+        vt = self.get_vision_tower()
+        if not vt.is_loaded:
+            vt.load_model()
+        if tower_sd is not None:
+            vt.vision_tower.load_state_dict(tower_sd, strict=False)
+        if adapter_sd is not None:
+            from ..weights import sub_state
+            self.model.mm_projector.load_state_dict(sub_state(adapter_sd, "mm_projector."), strict=True)
+            self.model.sampler.load_state_dict(sub_state(adapter_sd, "sampler."), strict=True)
+        return self
+
+    @torch.no_grad()
+    def encode_visual(self, images: torch.Tensor, split_sizes: Sequence[int], image_sizes=None, merge: Optional[str] = None):
+        """Router-free form of the sampler branch (what bench.py times): returns per image
+        ``(global [576,H], merged_local [n*144,H])`` in fp32."""
+        model = self.model
+        tower = model.get_vision_tower()
+        merge = merge or getattr(self.config, "mm_patch_merge_type", "flat")
+        feats = tower(images, out_dtype=torch.float32)
+        dev = feats.device
+        g_idx, l_idx = _split_indices(split_sizes, dev)
+        glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)
+        n_local = feats.shape[0] - len(split_sizes)
+        if n_local == 0:
+            return [(glob[i], glob.new_zeros((0, glob.shape[-1]))) for i in range(len(split_sizes))]
+        comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)
+        loc = model.mm_projector(comp, out_dtype=torch.float32)
+        g = model.sampler.grid_size
+        outs, lstart = [], 0
+        for i, s in enumerate(split_sizes):
+            n_i = s - 1
+            li = loc[lstart:lstart + n_i].contiguous()
+            lstart += n_i
+            merged = torch.empty((n_i * g * g, li.shape[-1]), dtype=torch.float32, device=dev)
+            if n_i > 0:
+                if merge == "spatial":
+                    nw, nh = get_anyres_image_grid_shape(image_sizes[i], self.config.image_grid_pinpoints,
+                                                         tower.config.image_size)
+                    ops.merge_rows(li, merged, 0, nw, nh, g, True)
+                else:
+                    ops.merge_rows(li, merged, 0, n_i, 1, g, False)
+            outs.append((glob[i], merged))
+        return outs

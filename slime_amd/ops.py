@@ -383,3 +383,40 @@ def tile_normalize(canvas_u8: torch.Tensor, crop: int, mean, std, out_dtype: tor
     _lib.check(lib.slime_tile_normalize(_ptr(canvas_u8.contiguous()), Hc, Wc, crop, m, s, out.data_ptr(),
                                         dtype_code(out_dtype), _stream()), "slime_tile_normalize")
     return out
+
+
+def router_scores(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """Cosine router scores [T] (fp32) for local tokens [T,H] against text embeddings [L,H]."""
+    lib = _lib.load()
+    _require_cuda(local_f, "local_f")
+    img = local_f.float().contiguous()
+    txt = text.to(device=img.device, dtype=torch.float32).contiguous()
+    T, H = img.shape
+    L = txt.shape[0]
+    m = None if mask is None else mask.to(device=img.device).ne(0).to(torch.uint8).contiguous()
+    scores = torch.empty((T,), dtype=torch.float32, device=img.device)
+    ws = torch.empty((L + H + 8,), dtype=torch.float32, device=img.device)
+    _lib.check(lib.slime_router_scores(img.data_ptr(), T, txt.data_ptr(), L, _ptr(m), H, scores.data_ptr(), ws.data_ptr(),
+                                       _stream()), "slime_router_scores")
+    return scores
+
+
+def router_select(scores: torch.Tensor, topp: float, temp: float, want_probs: bool = False):
+    """Device-side top-p selection; returns (keep_idx_buffer [T] int32, count [1] int32[, probs])."""
+    lib = _lib.load()
+    T = scores.shape[0]
+    keep = torch.empty((T,), dtype=torch.int32, device=scores.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=scores.device)
+    probs = torch.empty((T,), dtype=torch.float32, device=scores.device) if want_probs else None
+    _lib.check(lib.slime_router_select(scores.data_ptr(), T, float(temp), float(topp), keep.data_ptr(), cnt.data_ptr(),
+                                       _ptr(probs), _stream()), "slime_router_select")
+    return (keep, cnt, probs) if want_probs else (keep, cnt)
+
+
+def router_topp(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.Tensor], topp: float, temp: float) -> torch.Tensor:
+    """Indices (ascending, int64) of the local tokens the text-guided router keeps.  One D2H read of the
+    count -- the output length is data dependent (the reference syncs at ``nonzero`` too)."""
+    if local_f.shape[0] == 0:
+        return torch.zeros((0,), dtype=torch.long, device=local_f.device)
+    keep, cnt = router_select(router_scores(local_f, text, mask), topp, temp)
+    return keep[: int(cnt.item())].long()

@@ -1,0 +1,194 @@
+"""GPU tests of the reference-shaped plugin API (CLIPVisionTower, build_vision_projector,
+build_vision_sampler, encode_images) against the CPU oracle.  Tolerances as in test_gpu_path.py."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from PIL import Image
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 3e-3, torch.bfloat16: 1.5e-2}
+PIN = "[(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]"
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from slime_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _tiny_encoder(dev, dtype, embed=None, **cfg_over):
+    """SlimeVisualEncoder at the tiny fixture geometry (tower 128 wide / 3 layers, adapter 128 -> 256)."""
+    from slime_amd import weights as W
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
+    from slime_amd.image_processor import ClipImageProcessor
+    cfg = default_slime_config("synthetic:1", hidden_size=256, mm_hidden_size=128, **cfg_over)
+    enc = SlimeVisualEncoder(cfg, embed_tokens=embed)
+    vt = enc.get_vision_tower()
+    vt.vision_tower = HipCLIPVisionModel(W.TINY)              # tiny stand-in for the 'synthetic:' CLIP-L
+    vt.image_processor = ClipImageProcessor()
+    vt.is_loaded = True
+    tsd = W.make_tower_state_dict(W.TINY, seed=11)
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=12)
+    enc.load_visual_state(tsd, asd)
+    enc.to(dev)
+    vt.vision_tower.to(dtype)
+    return enc, W.strip_tower_prefix(tsd), asd
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_vision_tower_module(dev, dtype):
+    from slime_amd import weights as W
+    from oracle import slime_oracle as O
+    enc, tsd, _ = _tiny_encoder(dev, dtype)
+    tower = enc.get_vision_tower()
+    assert tower.dtype == dtype and tower.device.type == "cuda" and tower.hidden_size == 128
+    px = W.synthetic_pixels(9, seed=5)
+    ref = O.tower_forward(tsd, W.TINY, px)
+    out = tower(px.to(dev).to(dtype))                          # >= 8 crops: two-stream path
+    assert out.dtype == dtype and out.shape == (9, 576, 128)
+    assert rel_l2(out.float().cpu(), ref) < TOL[dtype] * 1.5
+    tower.vision_tower.two_streams = False
+    one = tower(px.to(dev).to(dtype))
+    assert torch.equal(one.cpu(), out.cpu())                   # stream split is bit-invisible
+    tower.vision_tower.two_streams = True
+    lst = tower([p for p in px[:3].to(dev)])                   # list branch: fp32 crops -> fp32 features
+    assert isinstance(lst, list) and lst[0].shape == (1, 576, 128) and lst[0].dtype == torch.float32
+    assert rel_l2(torch.cat(lst).cpu(), ref[:3]) < TOL[dtype]
+    tower.select_feature = "cls_patch"
+    assert tower(px[:2].to(dev)).shape == (2, 577, 128)
+    tower.select_feature = "patch"
+    assert tower.dummy_feature.shape == (1, 128)
+    hs = tower.vision_tower(px[:1].to(dev), output_hidden_states=True).hidden_states
+    assert len(hs) == W.TINY.num_hidden_layers + 1
+    assert torch.equal(tower.feature_select(SimpleNamespace(hidden_states=hs)).cpu(), tower(px[:1].to(dev)).cpu())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_projector_and_sampler_modules(dev, dtype):
+    from slime_amd import weights as W
+    from oracle import slime_oracle as O
+    enc, tsd, asd = _tiny_encoder(dev, dtype)
+    proj_sd, post_sd = W.sub_state(asd, "mm_projector."), W.sub_state(asd, "sampler.post_qformer.")
+    feats = O.tower_forward(tsd, W.TINY, W.synthetic_pixels(3, seed=22))
+    x = feats.to(dev).to(dtype)
+    m = enc.get_model()
+    g = m.mm_projector(x[0])                                   # [576, D] -> gated path, squeezed back
+    assert g.shape == (576, 256) and g.dtype == dtype
+    assert rel_l2(g.float().cpu(), O.gated_block_forward(proj_sd, x[0].float().cpu(), 1)) < TOL[dtype]
+    gb = m.mm_projector(x[:2])                                 # [N,576,D] batched gated path
+    assert rel_l2(gb.float().cpu(), O.gated_block_forward(proj_sd, x[:2].float().cpu(), 1)) < TOL[dtype]
+    comp = m.sampler.post_qformer(x[1:])
+    assert comp.shape == (2, 144, 128)
+    ref_comp = O.resampler_forward(post_sd, x[1:].float().cpu(), 1)
+    assert rel_l2(comp.float().cpu(), ref_comp) < TOL[dtype]
+    loc = m.mm_projector(comp)                                 # early-return branch: plain MLP
+    assert loc.shape == (2, 144, 256)
+    assert rel_l2(loc.float().cpu(), O.mlp_projector(proj_sd, comp.float().cpu())) < TOL[dtype]
+    m.mm_projector.learnable_gated = 1
+    e1 = m.mm_projector(x[0])
+    assert rel_l2(e1.float().cpu(), O.gated_block_forward(proj_sd, x[0].float().cpu(), 1, learnable_gated=1)) < TOL[dtype]
+    m.mm_projector.learnable_gated = -1
+
+
+def test_mlp2x_and_linear_projectors(dev):
+    from slime_amd.model.multimodal_projector.builder import build_vision_projector
+    import torch.nn.functional as F
+    cfg = SimpleNamespace(mm_projector_type="mlp2x_gelu", mm_hidden_size=128, hidden_size=256)
+    p = build_vision_projector(cfg).to(dev)
+    assert set(p.state_dict()) == {"0.weight", "0.bias", "2.weight", "2.bias"}
+    x = torch.randn(5, 144, 128, device=dev)
+    ref = F.linear(F.gelu(F.linear(x, p[0].weight, p[0].bias)), p[2].weight, p[2].bias)
+    assert rel_l2(p(x).cpu(), ref.cpu()) < 1.5e-2
+    lin = build_vision_projector(SimpleNamespace(mm_projector_type="linear", mm_hidden_size=128, hidden_size=256)).to(dev)
+    assert rel_l2(lin(x).cpu(), F.linear(x, lin.weight, lin.bias).cpu()) < 1.5e-2
+
+
+def test_router_kernels(dev):
+    from slime_amd import ops
+    from oracle import slime_oracle as O
+    g = torch.Generator().manual_seed(3)
+    for T, L, H, masked in ((288, 9, 256, True), (1008, 300, 4096, True), (576, 40, 256, False), (37, 5, 128, True)):
+        img = torch.randn(T, H, generator=g)
+        txt = torch.randn(L, H, generator=g)
+        mask = (torch.rand(L, generator=g) > 0.3) if masked else None
+        ref = O.router_cosine_scores(img, txt, mask)
+        sc = ops.router_scores(img.to(dev), txt.to(dev), None if mask is None else mask.to(dev))
+        assert rel_l2(sc.cpu(), ref) < 2e-5
+        for topp, temp in ((0.95, 1.0), (0.5, 0.3), (1.0, 1.0), (0.001, 1.0)):
+            keep, cnt, probs = ops.router_select(sc, topp, temp, want_probs=True)
+            n = int(cnt.item())
+            # selection logic must be EXACT given the device's own probabilities
+            p = probs.cpu()
+            sp, si = torch.sort(p, descending=True, stable=True)
+            k = int((torch.cumsum(sp, 0) <= topp).sum())
+            exp = si[: k + 1] if k < T else torch.arange(T)
+            assert n == exp.numel()
+            assert torch.equal(keep[:n].cpu().long(), exp.sort()[0])
+            assert rel_l2(p, torch.softmax(sc.cpu() / temp, 0)) < 1e-5
+        # end to end against the oracle's selection on its own scores (non-borderline data)
+        kept = ops.router_topp(img.to(dev), txt.to(dev), None if mask is None else mask.to(dev), 0.95, 1.0)
+        ref_keep = O.router_select(ref, 0.95, 1.0)
+        assert abs(kept.numel() - ref_keep.numel()) <= 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("sizes", [[(672, 672)], [(336, 336), (672, 672), (1344, 1344)]])
+def test_encode_images_vs_oracle(dev, dtype, sizes):
+    """Full sampler branch of encode_images (tower -> adapter -> merge -> router -> concat) on a batch
+    with ragged crop counts (2, 4, 6 local crops), every image against the oracle."""
+    from slime_amd import weights as W
+    from slime_amd.constants import IMAGE_TOKEN_INDEX
+    from oracle import slime_oracle as O
+    torch.manual_seed(0)
+    embed = nn.Embedding(2000, 256).to(dev)
+    enc, tsd, asd = _tiny_encoder(dev, dtype, embed=embed)
+    counts = [1 + O.anyres_grid_shape(s)[0] * O.anyres_grid_shape(s)[1] for s in sizes]
+    px = [W.synthetic_pixels(c, seed=50 + i) for i, c in enumerate(counts)]
+    images = torch.cat(px, 0).to(dev).to(dtype)
+    L = 12
+    ids = torch.randint(3, 1900, (len(sizes), L), device=dev)
+    ids[:, 4] = IMAGE_TOKEN_INDEX
+    am = torch.ones_like(ids)
+    am[:, -2:] = 0
+    feats, ss = enc.encode_images(images, input_ids=ids, split_sizes=counts, attention_mask=am, image_sizes=sizes)
+    assert ss == counts and len(feats) == len(sizes)
+    text, tmask = enc.get_pure_text_embedding(ids, am)
+    sep = embed(torch.tensor(enc.config.seperator, device=dev))
+    for i, s in enumerate(sizes):
+        ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i], s, text[i].float().cpu(), tmask[i].cpu(),
+                             separator=sep.float().cpu())
+        out = feats[i]
+        assert out.dim() == 3 and out.shape[0] == 1 and out.dtype == dtype
+        out = out[0].float().cpu()
+        assert rel_l2(out[:576], ref["global"]) < TOL[dtype] * 1.5
+        assert torch.allclose(out[576], sep.float().cpu().to(dtype).float())
+        n_ref = ref["router_keep"].numel()
+        assert abs((out.shape[0] - 577) - n_ref) <= 2, (out.shape, n_ref)      # top-p boundary may move by a token
+        if out.shape[0] - 577 == n_ref:
+            assert rel_l2(out[577:], ref["merged"][ref["router_keep"]]) < TOL[dtype] * 2
+    # router-free form used by bench.py
+    pairs = enc.encode_visual(images, counts, sizes, merge="spatial")
+    for i, s in enumerate(sizes):
+        ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i], s)
+        assert rel_l2(pairs[i][1].cpu(), ref["merged"]) < TOL[dtype] * 1.5
+
+
+def test_gpu_slicer_matches_pil_path(dev):
+    from slime_amd import mm_utils as M
+    from slime_amd.image_processor import ClipImageProcessor
+    proc = ClipImageProcessor()
+    for i, (w, h) in enumerate([(672, 672), (500, 900), (300, 200), (1344, 1344)]):
+        arr = np.random.default_rng(7 + i).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img = Image.fromarray(arr, "RGB")
+        ref = M.process_anyres_image(img, proc, PIN)
+        out = M.process_anyres_image_gpu(img, proc, PIN, dev)
+        assert out.shape == ref.shape
+        assert torch.equal(out.cpu(), ref), (w, h)            # same fp32 arithmetic order as the HF processor

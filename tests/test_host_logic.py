@@ -1,0 +1,131 @@
+"""CPU tests: slicer / pre-processing host logic against golden vectors produced by the reference,
+the C-ABI surface of the built library, and config/builder error behaviour.  No GPU."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from conftest import GOLDEN
+
+PIN = "[(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]"
+
+
+def test_abi_exports_every_header_symbol():
+    from slime_amd import _lib
+    lib = _lib.load()
+    syms = _lib.header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libslime_hip.so does not export {s}"
+    assert lib.slime_abi_version() == 1
+
+
+def test_grid_tables_match_reference():
+    from slime_amd import mm_utils as M, process_image as P
+    g = np.load(os.path.join(GOLDEN, "slicer_grid.npz"))
+    pts = [(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]
+    for (w, h), grid, uhd, sl, sbr in zip(g["sizes"], g["grid"], g["uhd"], g["slices"], g["select_best_resolution"]):
+        size = (int(w), int(h))
+        assert M.select_best_resolution_uhd(size, (336, 336)) == tuple(uhd), size
+        assert M.get_anyres_image_grid_shape(size, PIN, 336) == tuple(grid), size
+        assert M.get_anyres_image_grid_shape(size, pts, 336) == tuple(grid), size
+        assert P.cal_num_of_slices(*size) == tuple(sl), size
+        assert M.select_best_resolution(size, pts) == tuple(sbr), size
+    # probes recorded in SURVEY.md 8(a-1)
+    assert M.get_anyres_image_grid_shape((336, 336), PIN, 336) == (1, 2)
+    assert M.get_anyres_image_grid_shape((4000, 300), PIN, 336) == (7, 1)
+
+
+@pytest.mark.parametrize("mode", ["anyres", "pad", "any_res", "pad_then_devide"])
+def test_process_images_matches_reference_pixels(mode):
+    """Bit-exact per-crop checksums and sampled pixels of ``process_images`` for every slicing mode."""
+    from slime_amd import mm_utils as M
+    from slime_amd.image_processor import ClipImageProcessor
+    g = np.load(os.path.join(GOLDEN, "slicer_pixels.npz"))
+    proc = ClipImageProcessor()
+    assert np.allclose(proc.image_mean, g["image_mean"]) and np.allclose(proc.image_std, g["image_std"])
+    cfg = SimpleNamespace(image_aspect_ratio=mode, image_grid_pinpoints=PIN)
+    for i, (w, h) in enumerate(g["img_specs"]):
+        arr = np.random.default_rng(100 + i).integers(0, 256, (int(h), int(w), 3), dtype=np.uint8)
+        out = M.process_images([Image.fromarray(arr, "RGB")], proc, cfg)
+        out = out[0] if out.dim() == 5 else out
+        if out.dim() == 3:
+            out = out.unsqueeze(0)
+        assert tuple(out.shape) == tuple(g[f"img{i}_{mode}_shape"]), (i, mode)
+        flat = out.reshape(out.shape[0], -1).double()
+        assert np.array_equal(flat[:, g["sample_idx"]].float().numpy(), g[f"img{i}_{mode}_samples"]), (i, mode)
+        assert np.allclose(flat.sum(1).numpy(), g[f"img{i}_{mode}_sum"], rtol=0, atol=1e-6), (i, mode)
+        assert np.allclose((flat * flat).sum(1).numpy(), g[f"img{i}_{mode}_sumsq"], rtol=1e-12), (i, mode)
+
+
+def test_process_images_stacks_or_lists():
+    from slime_amd import mm_utils as M
+    from slime_amd.image_processor import ClipImageProcessor
+    proc = ClipImageProcessor()
+    cfg = SimpleNamespace(image_aspect_ratio="anyres", image_grid_pinpoints=PIN)
+    a = Image.fromarray(np.zeros((672, 672, 3), np.uint8))
+    b = Image.fromarray(np.zeros((1344, 1344, 3), np.uint8))
+    same = M.process_images([a, a], proc, cfg)
+    assert isinstance(same, torch.Tensor) and tuple(same.shape) == (2, 5, 3, 336, 336)
+    mixed = M.process_images([a, b], proc, cfg)
+    assert isinstance(mixed, list) and mixed[0].shape[0] == 5 and mixed[1].shape[0] == 1 + 6
+    with pytest.raises(Exception):
+        M.get_anyres_image_grid_shape((10, 10), "not a list", 336)
+
+
+def test_builders_reject_unknown_types():
+    from slime_amd.model.multimodal_encoder.builder import build_vision_tower
+    from slime_amd.model.multimodal_projector.builder import build_vision_projector
+    from slime_amd.model.multimodal_resampler.builder import build_vision_sampler, IdentityMap
+    with pytest.raises(ValueError, match="Unknown vision tower"):
+        build_vision_tower(SimpleNamespace(mm_vision_tower="not/a/tower", mm_vision_select_layer=-2))
+    with pytest.raises(ValueError, match="Unknown projector type"):
+        build_vision_projector(SimpleNamespace(mm_projector_type="bogus", mm_hidden_size=128, hidden_size=256))
+    assert isinstance(build_vision_sampler(SimpleNamespace(mm_resampler_type=None)), IdentityMap)
+    assert isinstance(build_vision_sampler(SimpleNamespace(mm_resampler_type="identity")), IdentityMap)
+
+
+def test_tower_module_contract_without_gpu():
+    """delay_load keeps config only; state-dict keys follow HF (both prefix generations load)."""
+    from slime_amd.model.multimodal_encoder.builder import build_vision_tower
+    from slime_amd import weights as W
+    args = SimpleNamespace(mm_vision_tower="synthetic:7", mm_vision_select_layer=-2, mm_vision_select_feature="patch")
+    t = build_vision_tower(args, delay_load=True)
+    assert not t.is_loaded and t.hidden_size == 1024 and t.num_patches == 576 and t.num_patches_per_side == 24
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
+    m = HipCLIPVisionModel(W.TINY)
+    sd = W.make_tower_state_dict(W.TINY, seed=3)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected
+    missing, unexpected = m.load_state_dict(W.strip_tower_prefix(sd), strict=False)      # transformers 5.x names
+    assert not missing and not unexpected
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    bad = SimpleNamespace(mm_vision_tower="synthetic:7", mm_vision_select_layer=-2, mm_vision_select_feature="nope")
+    t2 = build_vision_tower(bad, delay_load=True)
+    with pytest.raises(ValueError, match="Unexpected select feature"):
+        t2._keep_cls()
+
+
+def test_product_has_no_cpu_path():
+    """The HIP path must fail loudly rather than fall back: CPU tensors are rejected."""
+    from slime_amd import ops, _lib, weights as W
+    with pytest.raises((_lib.SlimeHipError, AssertionError, RuntimeError)):
+        pt = ops.pack_tower(W.make_tower_state_dict(W.TINY, seed=1), W.TINY, torch.bfloat16, "cpu")
+        ops.tower_forward(pt, torch.zeros(1, 3, 336, 336))
+
+
+def test_adapter_state_dict_roundtrip():
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
+    from slime_amd import weights as W
+    cfg = default_slime_config("synthetic:1", hidden_size=256, mm_hidden_size=128)
+    enc = SlimeVisualEncoder(cfg)
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=12)
+    enc.model.mm_projector.load_state_dict(W.sub_state(asd, "mm_projector."), strict=True)
+    enc.model.sampler.load_state_dict(W.sub_state(asd, "sampler."), strict=True)
+    keys = {"mm_projector." + k for k in enc.model.mm_projector.state_dict()} | {"sampler." + k for k in enc.model.sampler.state_dict()}
+    assert keys == set(asd.keys())
+    assert enc.model.mm_projector.w_gate.dtype == torch.bfloat16 and enc.model.sampler.post_qformer.pos_embed.dtype == torch.float16
+    assert enc.model.has_sampler and enc.model.sampler.grid_size == 12
