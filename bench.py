@@ -63,24 +63,46 @@ def event_time_ms(fn, iters=10, warm=2):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_roofline(dev, crops_per_launch):
-    """Time the four GEMM launch shapes of one tower layer (M = crops*577) and report the dominant."""
-    from slime_amd import ops, _lib
-    dt = torch.bfloat16
+# kernel id in the tower driver (include/slime_hip.h: slime_probe) -> (label, rocprof kernel name, N, K)
+PROBE_KERNELS = {
+    1: ("qkv_proj", "gemm_pp_kernel<BF16, 0, 0>", 3072, 1024),
+    3: ("out_proj+residual", "gemm_pp_kernel<BF16, 4, 0>", 1024, 1024),
+    5: ("fc1+quick_gelu", "gemm_pp_kernel<BF16, 1, 0>", 4096, 1024),
+    6: ("fc2+residual", "gemm_pp_kernel<BF16, 4, 1>", 1024, 4096),
+    2: ("attention", "attn_kernel<BF16, 64, 608, 8, 5>", 0, 0),
+}
+
+
+def kernel_roofline(step, vision_model, crops_per_launch, reps=3, layer=11):
+    """In-situ per-kernel durations: HIP events recorded by the tower driver (slime_vit_forward_ex probe) on
+    the launching stream, immediately around one kernel of one layer, while the real step runs (both
+    tower streams active).  Returns (dominant GEMM id, {id: stats})."""
     M = crops_per_launch * 577
-    shapes = {"qkv_proj": (3072, 1024, _lib.EPI_BIAS_T), "out_proj+residual": (1024, 1024, _lib.EPI_BIAS_RESID_F32),
-              "fc1+quick_gelu": (4096, 1024, _lib.EPI_BIAS_QUICKGELU_T), "fc2+residual": (1024, 4096, _lib.EPI_BIAS_RESID_F32)}
+    halves = 2 if vision_model.two_streams else 1
     per = {}
-    for name, (N, K, epi) in shapes.items():
-        a = torch.randn(M, K, device=dev).to(dt)
-        w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
-        b = torch.randn(N, device=dev)
-        out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi >= _lib.EPI_BIAS_F32 else dt)
-        ms = event_time_ms(lambda: ops.gemm(a, w, b, epi, out=out))
-        fl = 2.0 * M * N * K
-        per[name] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1), "M": M, "N": N, "K": K}
-        del a, w, b, out
-    dom = max(per, key=lambda k: per[k]["ms"])
+    for kid, (label, name, N, K) in PROBE_KERNELS.items():
+        evs = []
+        for slot in range(halves):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record()                       # force creation of the HIP events
+            vision_model.packed(-2, slot).probe = (layer, kid, e0, e1)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(reps):
+            step()
+            torch.cuda.synchronize()
+            ms.extend(e0.elapsed_time(e1) for e0, e1 in evs)
+        for slot in range(halves):
+            vision_model.packed(-2, slot).probe = None
+        avg = sum(ms) / len(ms)
+        if kid == 2:
+            fl = 4.0 * crops_per_launch * 16 * 577 * 577 * 64
+        else:
+            fl = 2.0 * M * N * K
+        per[kid] = {"label": label, "rocprof_name": name, "ms": round(avg, 4), "min_ms": round(min(ms), 4),
+                    "tflops": round(fl / avg / 1e9, 1), "gflop_per_launch": round(fl / 1e9, 2), "M": M, "N": N, "K": K}
+    dom = max((k for k in per if k != 2), key=lambda k: per[k]["ms"])
     return dom, per
 
 
@@ -187,7 +209,7 @@ def main():
         step_gf = n_local * GF_VIT_PER_CROP + IMAGES_PER_GPU * GF_GLOBAL_PER_IMAGE + IMAGES_PER_GPU * LOCAL_CROPS * GF_LOCAL_PER_CROP
         path_tflops = step_gf * world / (elapsed / args.steps) / 1e3
         halves = 2 if tower.vision_tower.two_streams else 1
-        dom, per = kernel_roofline(dev, n_local // halves)
+        dom, per = kernel_roofline(step, tower.vision_tower, n_local // halves)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.isfile(pmc):
@@ -207,10 +229,14 @@ def main():
                        "tower_streams": halves},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
                           "gflop_per_step_per_gpu": round(step_gf, 1)},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_pp_kernel<bf16> ({dom}, M={per[dom]['M']} N={per[dom]['N']} K={per[dom]['K']})",
+            "roofline": {"bound": "mfma",
+                         "kernel": f"{per[dom]['rocprof_name']} ({per[dom]['label']}, M={per[dom]['M']} N={per[dom]['N']} K={per[dom]['K']})",
                          "achieved": per[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(per[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "launch_ms": per[dom]["ms"], "all_gemm_shapes": per},
+                         "launch_ms": per[dom]["ms"], "gflop_per_launch": per[dom]["gflop_per_launch"],
+                         "method": "HIP events recorded by the tower driver around the kernel (layer 11) on its launching stream, "
+                                   "inside the real step with both tower streams active; mean over 3 steps x 2 streams",
+                         "kernels_in_situ": {v["label"]: {k: v[k] for k in ("rocprof_name", "ms", "min_ms", "tflops")} for v in per.values()}},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd)

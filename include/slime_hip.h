@@ -151,12 +151,22 @@ typedef struct {
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
 
+/* Optional in-situ timing probe: slime_vit_forward_ex records the HIP events `start` / `stop` (hipEvent_t,
+ * owned by the caller) immediately before / after the launch of one kernel of one layer, on the call's
+ * stream.  kernel: 0 LN1, 1 qkv GEMM, 2 attention, 3 out_proj GEMM, 4 LN2, 5 fc1 GEMM, 6 fc2 GEMM. */
+typedef struct { int layer; int kernel; void* start; void* stop; } slime_probe;
+
 /* pixels [n,3,image,image] -> out [n, P(+1 if keep_cls), hidden] in out_dtype (BF16/F16/F32).
  * If hidden_f32 is non-NULL it also receives the fp32 residual stream [n, 1+P, hidden]
  * (the selected hidden state before the cls drop / cast). */
 int slime_vit_forward(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n_crops,
                       void* out, int out_dtype, int keep_cls, float* hidden_f32,
                       void* ws, size_t ws_bytes, void* stream);
+
+/* Same, with an optional probe (NULL = none). */
+int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n_crops,
+                         void* out, int out_dtype, int keep_cls, float* hidden_f32,
+                         void* ws, size_t ws_bytes, void* stream, const slime_probe* probe);
 
 /* ------------------------------------------------------------------------------------------------
  * Resampler (sampler.py:91-173) with kv_proj = proj = Identity, as post_qformer / GatedBlock.attn

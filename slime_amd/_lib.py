@@ -45,6 +45,10 @@ class MlpDesc(C.Structure):
                 ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p)]
 
 
+class Probe(C.Structure):
+    _fields_ = [("layer", c_int), ("kernel", c_int), ("start", c_void_p), ("stop", c_void_p)]
+
+
 _P = C.POINTER
 _SIGNATURES = {
     "slime_abi_version": (c_int, []),
@@ -66,6 +70,8 @@ _SIGNATURES = {
     "slime_vit_workspace_bytes": (c_size_t, [_P(VitDesc), c_int]),
     "slime_vit_forward": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
+    "slime_vit_forward_ex": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                     c_size_t, c_void_p, _P(Probe)]),
     "slime_resampler_workspace_bytes": (c_size_t, [_P(ResamplerDesc), c_int]),
     "slime_resampler_forward": (c_int, [_P(ResamplerDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),

@@ -85,6 +85,20 @@ extern "C" size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops
 extern "C" int slime_vit_forward(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out,
                                  int out_dtype, int keep_cls, float* hidden_f32, void* ws, size_t ws_bytes,
                                  void* stream) {
+    return slime_vit_forward_ex(d, pixels, pix_dtype, n, out, out_dtype, keep_cls, hidden_f32, ws, ws_bytes, stream, nullptr);
+}
+
+#define PROBED(kid, call)                                                                             \
+    do {                                                                                              \
+        const bool on_ = probe && probe->layer == l && probe->kernel == (kid);                        \
+        if (on_ && probe->start) (void)hipEventRecord((hipEvent_t)probe->start, (hipStream_t)stream);       \
+        TRY(call);                                                                                    \
+        if (on_ && probe->stop) (void)hipEventRecord((hipEvent_t)probe->stop, (hipStream_t)stream);          \
+    } while (0)
+
+extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out,
+                                    int out_dtype, int keep_cls, float* hidden_f32, void* ws, size_t ws_bytes,
+                                    void* stream, const slime_probe* probe) {
     TRY(vit_validate(d));
     SLIME_REQUIRE(pixels && n > 0, "vit: bad input");
     SLIME_REQUIRE(out || hidden_f32, "vit: no output requested");
@@ -116,17 +130,17 @@ extern "C" int slime_vit_forward(const slime_vit_desc* d, const void* pixels, in
         const char* w_o = (const char*)d->w_o + (size_t)l * D * D * 2;
         const char* w_fc1 = (const char*)d->w_fc1 + (size_t)l * F * D * 2;
         const char* w_fc2 = (const char*)d->w_fc2 + (size_t)l * D * F * 2;
-        TRY(slime_layernorm(h, D, M, D, d->ln1_w + (size_t)l * D, d->ln1_b + (size_t)l * D, d->eps, 1, nullptr, xn,
-                            nullptr, nullptr, 0, dt, stream));
-        TRY(slime_gemm(xn, D, w_qkv, d->b_qkv + (size_t)l * 3 * D, qkv, 3 * D, M, 3 * D, D, dt, SLIME_EPI_BIAS_T, stream));
-        TRY(slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
-                            qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
-                            dt, stream));
-        TRY(slime_gemm(ctx, D, w_o, d->b_o + (size_t)l * D, h, D, M, D, D, dt, SLIME_EPI_BIAS_RESID_F32, stream));
-        TRY(slime_layernorm(h, D, M, D, d->ln2_w + (size_t)l * D, d->ln2_b + (size_t)l * D, d->eps, 1, nullptr, xn,
-                            nullptr, nullptr, 0, dt, stream));
-        TRY(slime_gemm(xn, D, w_fc1, d->b_fc1 + (size_t)l * F, ff, F, M, F, D, dt, SLIME_EPI_BIAS_QUICKGELU_T, stream));
-        TRY(slime_gemm(ff, F, w_fc2, d->b_fc2 + (size_t)l * D, h, D, M, D, F, dt, SLIME_EPI_BIAS_RESID_F32, stream));
+        PROBED(0, slime_layernorm(h, D, M, D, d->ln1_w + (size_t)l * D, d->ln1_b + (size_t)l * D, d->eps, 1, nullptr, xn,
+                                  nullptr, nullptr, 0, dt, stream));
+        PROBED(1, slime_gemm(xn, D, w_qkv, d->b_qkv + (size_t)l * 3 * D, qkv, 3 * D, M, 3 * D, D, dt, SLIME_EPI_BIAS_T, stream));
+        PROBED(2, slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
+                                  qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
+                                  dt, stream));
+        PROBED(3, slime_gemm(ctx, D, w_o, d->b_o + (size_t)l * D, h, D, M, D, D, dt, SLIME_EPI_BIAS_RESID_F32, stream));
+        PROBED(4, slime_layernorm(h, D, M, D, d->ln2_w + (size_t)l * D, d->ln2_b + (size_t)l * D, d->eps, 1, nullptr, xn,
+                                  nullptr, nullptr, 0, dt, stream));
+        PROBED(5, slime_gemm(xn, D, w_fc1, d->b_fc1 + (size_t)l * F, ff, F, M, F, D, dt, SLIME_EPI_BIAS_QUICKGELU_T, stream));
+        PROBED(6, slime_gemm(ff, F, w_fc2, d->b_fc2 + (size_t)l * D, h, D, M, D, F, dt, SLIME_EPI_BIAS_RESID_F32, stream));
     }
     if (out) {
         // feature_select: 'patch' drops the class token (clip_encoder.py:38-39), cast to out dtype (:52,56)

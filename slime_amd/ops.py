@@ -113,6 +113,7 @@ class PackedTower:
     tensors: Dict[str, torch.Tensor]
     desc: _lib.VitDesc
     ws: Workspace = field(default_factory=Workspace)
+    probe: Optional[tuple] = None        # (layer, kernel id, start event, stop event): in-situ kernel timing
 
     @property
     def device(self):
@@ -203,9 +204,13 @@ def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[tor
     need = lib.slime_vit_workspace_bytes(C.byref(pt.desc), n)
     ws = pt.ws.get(need, pixels.device)
     base = (ws.data_ptr() + 255) // 256 * 256
-    _lib.check(lib.slime_vit_forward(C.byref(pt.desc), pixels.data_ptr(), dtype_code(pixels.dtype), n, out.data_ptr(),
-                                     dtype_code(out_dtype), int(keep_cls), _ptr(hidden), base,
-                                     ws.numel() - (base - ws.data_ptr()), _stream()), "slime_vit_forward")
+    probe = None
+    if pt.probe is not None:
+        layer, kernel, e0, e1 = pt.probe
+        probe = C.byref(_lib.Probe(int(layer), int(kernel), e0.cuda_event, e1.cuda_event))
+    _lib.check(lib.slime_vit_forward_ex(C.byref(pt.desc), pixels.data_ptr(), dtype_code(pixels.dtype), n, out.data_ptr(),
+                                        dtype_code(out_dtype), int(keep_cls), _ptr(hidden), base,
+                                        ws.numel() - (base - ws.data_ptr()), _stream(), probe), "slime_vit_forward")
     return (out, hidden) if want_hidden else out
 
 

@@ -22,6 +22,6 @@ def golden_dir():
 def rel_l2(a, b):
     """||a-b|| / ||b|| in float64."""
     import torch
-    a = torch.as_tensor(a).double()
-    b = torch.as_tensor(b).double()
+    a = torch.as_tensor(a).detach().double()
+    b = torch.as_tensor(b).detach().double()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -1,5 +1,7 @@
 """GPU tests of the reference-shaped plugin API (CLIPVisionTower, build_vision_projector,
-build_vision_sampler, encode_images) against the CPU oracle.  Tolerances as in test_gpu_path.py."""
+build_vision_sampler, encode_images) against the CPU oracle.  Per-stage tolerances as in test_gpu_path.py
+(fp16 3e-3, bf16 1.5e-2, rel-L2 vs the fp32 oracle); end-of-chain tensors (pixels rounded to T -> tower ->
+post_qformer -> MLP) are allowed 2x that."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -162,6 +164,7 @@ def test_encode_images_vs_oracle(dev, dtype, sizes):
     assert ss == counts and len(feats) == len(sizes)
     text, tmask = enc.get_pure_text_embedding(ids, am)
     sep = embed(torch.tensor(enc.config.seperator, device=dev))
+    pairs = enc.encode_visual(images, counts, sizes, merge="spatial")           # device tokens before the router
     for i, s in enumerate(sizes):
         ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i], s, text[i].float().cpu(), tmask[i].cpu(),
                              separator=sep.float().cpu())
@@ -170,15 +173,23 @@ def test_encode_images_vs_oracle(dev, dtype, sizes):
         out = out[0].float().cpu()
         assert rel_l2(out[:576], ref["global"]) < TOL[dtype] * 1.5
         assert torch.allclose(out[576], sep.float().cpu().to(dtype).float())
-        n_ref = ref["router_keep"].numel()
-        assert abs((out.shape[0] - 577) - n_ref) <= 2, (out.shape, n_ref)      # top-p boundary may move by a token
-        if out.shape[0] - 577 == n_ref:
-            assert rel_l2(out[577:], ref["merged"][ref["router_keep"]]) < TOL[dtype] * 2
+        # router: the oracle's rule applied to the DEVICE's merged tokens must select the same set, up to
+        # near-ties at the top-p cut (the scores agree to ~1e-6, the selection is discontinuous)
+        merged_dev = pairs[i][1].cpu()
+        assert rel_l2(merged_dev, ref["merged"]) < TOL[dtype] * 2
+        keep_ref = O.router_select(O.router_cosine_scores(merged_dev, text[i].float().cpu(), tmask[i].cpu()), 0.95, 1.0)
+        rows = out[577:]
+        assert abs(rows.shape[0] - keep_ref.numel()) <= 2
+        cand = merged_dev.to(dtype).float()
+        # every emitted row is one of the merged rows, in ascending order
+        idx = torch.cdist(rows, cand).argmin(1)                   # cdist is only used to identify the rows
+        assert torch.equal(rows, cand[idx]) and bool((idx[1:] > idx[:-1]).all())
+        sym = set(idx.tolist()) ^ set(keep_ref.tolist())
+        assert len(sym) <= 4, sorted(sym)
     # router-free form used by bench.py
-    pairs = enc.encode_visual(images, counts, sizes, merge="spatial")
     for i, s in enumerate(sizes):
         ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i], s)
-        assert rel_l2(pairs[i][1].cpu(), ref["merged"]) < TOL[dtype] * 1.5
+        assert rel_l2(pairs[i][1].cpu(), ref["merged"]) < TOL[dtype] * 2
 
 
 def test_gpu_slicer_matches_pil_path(dev):
