@@ -83,6 +83,9 @@ _SIGNATURES = {
     # tuning hooks (not part of the reference-facing ABI)
     "slime_gemm_force_tile": (None, [c_int]),
     "slime_gemm_set_sched": (None, [c_int]),
+    "slime_gemm_set_ablation": (None, [c_int]),
+    "slime_gemm_set_stagger": (None, [c_int]),
+    "slime_gemm_set_debug": (None, [c_void_p]),
 }
 
 _lib = None

@@ -24,40 +24,134 @@
 struct GemmArgs {
     const char* A; const char* B; const float* bias; void* C;
     int lda, ldc, M, N, K;
+    int stagger;      // first-round start stagger of the ping-pong kernel, in units of 64*16 cycles per step
+    unsigned long long* dbg;   // ABL & 8 builds only: 4 s_memtime stamps per workgroup
 };
 
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
 
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, float* v) {
-    if (g.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col);
-        const float4 b1 = *reinterpret_cast<const float4*>(g.bias + col + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    }
-    if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+// Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
+// columns starting at col_base + 32 p of row row_base + 16 i.
+//
+// What the s_memtime stamps showed (256x256 tile, 59k-cycle workgroup at K = 1024): a naive
+// "for each 8-column group: load bias/residual, add, store" epilogue costs 13k cycles.  On CDNA4 vmcnt
+// counts stores as well as loads, bias/residual may alias C so loads cannot be hoisted over stores,
+// and a per-row `if (row < M)` makes the compiler open every block with a conservative vmcnt(0) that
+// also drains the previous block's stores.  Hence:
+//   * FULL tiles (every row < M; all but the last row tile) take a branch-free path;
+//   * the bias is loaded once up front; results are formed in place in the accumulators (distinct
+//     registers per store) and stored back to back;
+//   * the fp32 residual is fetched in register double-buffered batches, one batch ahead of the stores.
+template <typename T, int EPI, int MI, int NI, bool FULL>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI][NI], const int row_base, const int col_base) {
+    constexpr int NP = NI / 2;
+    float bias[NP][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)   // x * sigmoid(1.702 x)
-            v[i] = v[i] * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * v[i]));
-    } else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) {
+    for (int p = 0; p < NP; ++p) {
+        if (g.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col_base + 32 * p);
+            const float4 b1 = *reinterpret_cast<const float4*>(g.bias + col_base + 32 * p + 4);
+            bias[p][0] = b0.x; bias[p][1] = b0.y; bias[p][2] = b0.z; bias[p][3] = b0.w;
+            bias[p][4] = b1.x; bias[p][5] = b1.y; bias[p][6] = b1.z; bias[p][7] = b1.w;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)   // exact (erf) GELU, as nn.GELU()
-            v[i] = 0.5f * v[i] * (1.0f + erff(v[i] * 0.70710678118654752440f));
-    }
-    if constexpr (EpiOutIsT<EPI>::value) {
-        char* p = reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col) * 2;
-        *reinterpret_cast<u32x4*>(p) = pack8<T>(v);
-    } else {
-        float* p = reinterpret_cast<float*>(g.C) + (size_t)row * g.ldc + col;
-        if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32) {
-            const float4 h0 = *reinterpret_cast<const float4*>(p);
-            const float4 h1 = *reinterpret_cast<const float4*>(p + 4);
-            v[0] += h0.x; v[1] += h0.y; v[2] += h0.z; v[3] += h0.w;
-            v[4] += h1.x; v[5] += h1.y; v[6] += h1.z; v[7] += h1.w;
+            for (int j = 0; j < 8; ++j) bias[p][j] = 0.f;
         }
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    auto in_range = [&](int row) { return FULL || row < g.M; };
+    if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32) {
+        constexpr int BATCH = (MI >= 2) ? 2 : 1;          // 16-row steps per residual batch
+        constexpr int NB = MI / BATCH;
+        float4 hb[2][BATCH][NP][2];
+        float* C = reinterpret_cast<float*>(g.C);
+        auto load_batch = [&](int b, int buf) {
+#pragma unroll
+            for (int ii = 0; ii < BATCH; ++ii) {
+                int row = row_base + (b * BATCH + ii) * 16;
+                if constexpr (!FULL) row = min(row, g.M - 1);                       // clamp: value unused past M
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float* src = C + (size_t)row * g.ldc + col_base + 32 * p;
+                    hb[buf][ii][p][0] = *reinterpret_cast<const float4*>(src);
+                    hb[buf][ii][p][1] = *reinterpret_cast<const float4*>(src + 4);
+                }
+            }
+        };
+        load_batch(0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) load_batch(b + 1, (b + 1) & 1);           // residual loads run one batch ahead of the stores
+#pragma unroll
+            for (int ii = 0; ii < BATCH; ++ii) {
+                const int i = b * BATCH + ii;
+                const int row = row_base + i * 16;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float4 h0 = hb[b & 1][ii][p][0], h1 = hb[b & 1][ii][p][1];
+                    acc[i][2 * p][0] += bias[p][0] + h0.x; acc[i][2 * p][1] += bias[p][1] + h0.y;
+                    acc[i][2 * p][2] += bias[p][2] + h0.z; acc[i][2 * p][3] += bias[p][3] + h0.w;
+                    acc[i][2 * p + 1][0] += bias[p][4] + h1.x; acc[i][2 * p + 1][1] += bias[p][5] + h1.y;
+                    acc[i][2 * p + 1][2] += bias[p][6] + h1.z; acc[i][2 * p + 1][3] += bias[p][7] + h1.w;
+                    if (in_range(row)) {
+                        float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
+                        *reinterpret_cast<f32x4*>(o) = acc[i][2 * p];
+                        *reinterpret_cast<f32x4*>(o + 4) = acc[i][2 * p + 1];
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = acc[i][2 * p][j] + bias[p][j], b = acc[i][2 * p + 1][j] + bias[p][4 + j];
+                    if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {          // x*sigmoid(1.702x)
+                        a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
+                        b = b * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * b));
+                    } else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) {        // exact GELU
+                        a = 0.5f * a * (1.0f + erff(a * 0.70710678118654752440f));
+                        b = 0.5f * b * (1.0f + erff(b * 0.70710678118654752440f));
+                    }
+                    acc[i][2 * p][j] = a; acc[i][2 * p + 1][j] = b;
+                }
+        if constexpr (EpiOutIsT<EPI>::value) {
+            u32x4 packed[MI][NP];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    packed[i][p][0] = T::pack2(acc[i][2 * p][0], acc[i][2 * p][1]);
+                    packed[i][p][1] = T::pack2(acc[i][2 * p][2], acc[i][2 * p][3]);
+                    packed[i][p][2] = T::pack2(acc[i][2 * p + 1][0], acc[i][2 * p + 1][1]);
+                    packed[i][p][3] = T::pack2(acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]);
+                }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = row_base + i * 16;
+                if (in_range(row)) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = packed[i][p];
+                }
+            }
+        } else {
+            float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = row_base + i * 16;
+                if (in_range(row)) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
+                        *reinterpret_cast<f32x4*>(o) = acc[i][2 * p];
+                        *reinterpret_cast<f32x4*>(o + 4) = acc[i][2 * p + 1];
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -196,20 +290,8 @@ gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds, per (mi, tile pair), 8 consecutive columns of one row ------------
-    const int q = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int row = m0 + wm * TM + i * 16 + (lane & 15);
-        if (row < g.M) {
-#pragma unroll
-            for (int p = 0; p < NI / 2; ++p) {
-                const int col = n0 + wn * TN + 32 * p + 8 * q;
-                float v[8] = {acc[i][2 * p][0], acc[i][2 * p][1], acc[i][2 * p][2], acc[i][2 * p][3],
-                              acc[i][2 * p + 1][0], acc[i][2 * p + 1][1], acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]};
-                epilogue_store<T, EPI>(g, row, col, v);
-            }
-        }
-    }
+    if (m0 + BM <= g.M) epilogue_wave<T, EPI, MI, NI, true>(g, acc, m0 + wm * TM + (lane & 15), n0 + wn * TN + 8 * (lane >> 4));
+    else epilogue_wave<T, EPI, MI, NI, false>(g, acc, m0 + wm * TM + (lane & 15), n0 + wn * TN + 8 * (lane >> 4));
 }
 
 
@@ -246,7 +328,9 @@ gemm_kernel(GemmArgs g) {
 
 // KTAG only splits the symbol name by contraction-length class (K >= 2048: the fc2 shape) so that
 // profilers report the short-K and long-K launches of one epilogue as separate kernels.
-template <typename T, int EPI, int KTAG>
+// ABL (timing ablations only, results are wrong for ABL != 0): bit0 = no LDS-DMA in the main loop,
+// bit1 = no fragment ds_reads in the main loop, bit2 = no barriers in the main loop.
+template <typename T, int EPI, int KTAG, int ABL = 0>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
@@ -268,6 +352,15 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     const int tn = (pid % in_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    // De-synchronise the CUs: all workgroups of a round would otherwise run their HBM-bound prologue
+    // (112 KB in) and epilogue (128-256 KB out) phases at the same instant.  The first round starts
+    // staggered over 8 steps; later rounds inherit the skew (a CU takes its next workgroup when it is free).
+    if (g.stagger > 0 && blockIdx.x < 256) {
+        const int steps = (blockIdx.x >> 3) & 7;
+        for (int i = 0; i < steps * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
+    if constexpr ((ABL & 8) != 0) t_start = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;            // group == A half (wm)
@@ -332,6 +425,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     PP_BARRIER();
+    if constexpr ((ABL & 8) != 0) t_pro = __builtin_amdgcn_s_memtime();
     if (grp == 1) PP_BARRIER();                          // group 1 runs one slot behind
 
     u32x4 af[4][2], bf[2][2][2];
@@ -341,21 +435,21 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         for (int p = 0; p < 4; ++p) {
             const int mh = (p >> 1), nh = (p == 1 || p == 2) ? 1 : 0;   // (0,0) (0,1) (1,1) (1,0)
             // ---------------- L section ----------------
-            if (p == 0) {
+            if ((p == 0) && (!(ABL & 2) || t == 0)) {
 #pragma unroll
                 for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
                         bf[0][nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + (nj * 16) * 128);
             }
-            if (p == 0 || p == 2) {
+            if ((p == 0 || p == 2) && (!(ABL & 2) || t == 0)) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
                         af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (mh * 64 + mi * 16) * 128);
             }
-            if (p == 1) {
+            if ((p == 1) && (!(ABL & 2) || t == 0)) {
 #pragma unroll
                 for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
@@ -365,14 +459,14 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             {
                 const int kind = (p == 0) ? 3 : p - 1;    // L0: A rows 64..127 (tile t+1); L1..L3: tile t+2
                 const int itile = (p == 0) ? t + 1 : t + 2;
-                if (itile < nk) {
+                if (itile < nk && !(ABL & 1)) {
                     issue(kind, itile);
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
             }
-            PP_BARRIER();
+            if (!(ABL & 4)) PP_BARRIER();
             // ---------------- M section ----------------
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -383,31 +477,246 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
                     for (int nj = 0; nj < 2; ++nj)
                         acc[mh * 4 + mi][nh * 2 + nj] = T::mfma16(bf[nh][nj][ks], af[mi][ks], acc[mh * 4 + mi][nh * 2 + nj]);
             __builtin_amdgcn_s_setprio(0);
-            PP_BARRIER();
+            if (!(ABL & 4)) PP_BARRIER();
         }
     }
     if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
+    if constexpr ((ABL & 8) != 0) t_loop = __builtin_amdgcn_s_memtime();
 
-    const int q = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = m0 + grp * 128 + i * 16 + (lane & 15);
-        if (row < g.M) {
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int col = n0 + wn * 64 + 32 * p + 8 * q;
-                float v[8] = {acc[i][2 * p][0], acc[i][2 * p][1], acc[i][2 * p][2], acc[i][2 * p][3],
-                              acc[i][2 * p + 1][0], acc[i][2 * p + 1][1], acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]};
-                epilogue_store<T, EPI>(g, row, col, v);
-            }
+    if (m0 + BM <= g.M) epilogue_wave<T, EPI, 8, 4, true>(g, acc, m0 + grp * 128 + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
+    else epilogue_wave<T, EPI, 8, 4, false>(g, acc, m0 + grp * 128 + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
+    if constexpr ((ABL & 8) != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && g.dbg) {
+            unsigned long long* d = g.dbg + (size_t)blockIdx.x * 4;
+            d[0] = t_start; d[1] = t_pro; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
         }
     }
 }
 
+
+// ================================================================================================
+// Persistent ping-pong kernel: the ping-pong kernel above, but a workgroup walks its output tiles
+// (tile = blockIdx.x, + gridDim.x, ...) as ONE continuous k-tile stream.
+//
+// Why (s_memtime stamps, 256x256 tiles at K = 1024): a one-tile workgroup spends 2.8k cycles in its
+// prologue (first DMA latency), 43k in the main loop and 9-13k in the epilogue, and because all CUs run
+// in lock step the 256 x 128..256 KB of epilogue stores hit HBM as one burst while the memory system
+// idles during main loops.  Here
+//   * the LDS-DMA schedule never drains between tiles: "tile t+1 / t+2" of the issue table simply
+//     runs into the next output tile, so its k-tiles 0/1 are already in LDS when the current tile ends;
+//   * the epilogue only ISSUES its stores; they drain under the next tile's MFMAs.  vmcnt counts stores
+//     too and loads/stores may retire out of order with respect to each other, so counted waits are
+//     only used where nothing older than the wanted loads can be pending: the wave drains its DMA
+//     (vmcnt(0)) right before the epilogue, issues the stores, skips the (unneeded) waits of the next
+//     tile's first k-tile, and resumes the counted vmcnt(8) at k-tile 1 -- by then the stores have had
+//     >= 4 slots plus the epilogue arithmetic to complete.
+// ================================================================================================
 template <typename T, int EPI, int KTAG>
+__global__ void __launch_bounds__(512) gemm_ppp_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int GROUP_M = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int ntiles = tiles_m * tiles_n;
+    const int nk = g.K / BK;                                 // >= 2 (checked by the launcher)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // logical tile index -> (m0, n0): XCD-first remap (L & 7 is the XCD for every tile of this workgroup
+    // because gridDim.x is a multiple of 8 or equals ntiles), then GROUP_M swizzle.
+    auto tile_origin = [&](int L, int& m0, int& n0) {
+        const int xcd = L & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        const int in_group = GROUP_M * tiles_n;
+        const int first_m = (pid / in_group) * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (pid % in_group) % gsz) * BM;
+        n0 = ((pid % in_group) / gsz) * BN;
+    };
+
+    // ---- DMA pieces of this wave (see gemm_pp_kernel): kinds 0/3 = A quarters, 1/2 = B half parts ----
+    int dst[4][2];
+    unsigned b_voff[2][2];                                   // tile independent
+    int a_row[2][2];                                         // row inside the tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = wn * 2 + j;
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa) {
+            a_row[qa][j] = grp * 128 + qa * 64 + piece * 8 + lrow;
+            dst[qa ? 3 : 0][j] = (grp * 128 + qa * 64 + piece * 8) * 128;
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            const int chunk = grp * 2 + (piece >> 2), sub = piece & 3;
+            const int rho = chunk * 64 + hb * 32 + sub * 8 + lrow;
+            const int nl = rho & 15;
+            const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
+            b_voff[hb][j] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+            dst[1 + hb][j] = A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
+        }
+    }
+    struct TileSrc { unsigned a_voff[2][2]; size_t b_base; int m0, n0; };
+    auto make_src = [&](int L, TileSrc& ts) {
+        tile_origin(L, ts.m0, ts.n0);
+#pragma unroll
+        for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                ts.a_voff[qa][j] = (unsigned)min(ts.m0 + a_row[qa][j], g.M - 1) * (unsigned)g.lda * 2u + lchunk * 16;
+        ts.b_base = (size_t)ts.n0 * g.K * 2;
+    };
+    // 2 pieces of `kind` for k-tile kt of tile `ts`, into stage buffer `buf`
+    auto issue = [&](const TileSrc& ts, int kind, int kt, int buf) {
+        char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const char* src = (kind == 0 || kind == 3)
+                                  ? g.A + (size_t)ts.a_voff[kind == 3][j] + (size_t)kt * (BK * 2)
+                                  : g.B + ts.b_base + (size_t)b_voff[kind - 1][j] + (size_t)kt * (BK * 2);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src), LDS_PTR(base + dst[kind][j]), 16, 0, 0);
+        }
+    };
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sw = ((ks * 4 + lq) ^ (lane & 7)) << 4;
+        a_off[ks] = (grp * 128 + li) * 128 + sw;
+        b_off[ks] = A_BYTES + (wn * 64 + li) * 128 + sw;
+    }
+
+    TileSrc cur, nxt;
+    int L = blockIdx.x;
+    make_src(L, cur);
+    // prologue of the first tile: all of k-tile 0 and the k-tile-1 pieces of kinds 0..2
+    issue(cur, 0, 0, 0); issue(cur, 1, 0, 0); issue(cur, 2, 0, 0); issue(cur, 3, 0, 0);
+    issue(cur, 0, 1, 1); issue(cur, 1, 1, 1); issue(cur, 2, 1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    int gk = 0;                                              // global k-tile counter of tile start (buffer parity)
+    u32x4 af[4][2], bf[2][2][2];
+    while (true) {
+        const int Ln = L + gridDim.x;
+        const bool has_next = Ln < ntiles;
+        if (has_next) make_src(Ln, nxt);
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        PP_BARRIER();                                        // k-tiles 0/1 of this tile visible to all waves
+        if (grp == 1) PP_BARRIER();                          // group 1 runs one slot behind
+        for (int t = 0; t < nk; ++t) {
+            const char* sb = smem + ((gk + t) & 1) * STAGE;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int mh = (p >> 1), nh = (p == 1 || p == 2) ? 1 : 0;
+                if (p == 0) {
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            bf[0][nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + (nj * 16) * 128);
+                }
+                if (p == 0 || p == 2) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (mh * 64 + mi * 16) * 128);
+                }
+                if (p == 1) {
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            bf[1][nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + (32 + nj * 16) * 128);
+                }
+                {
+                    const int kind = (p == 0) ? 3 : p - 1;
+                    const int itile = (p == 0) ? t + 1 : t + 2;
+                    const int buf = (gk + itile) & 1;
+                    bool issued = true;
+                    if (itile < nk) issue(cur, kind, itile, buf);
+                    else if (has_next) issue(nxt, kind, itile - nk, buf);
+                    else issued = false;
+                    if (!issued) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (t > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    // t == 0: every k-tile-0/1 piece this tile reads before k-tile 1 was drained before the
+                    // previous epilogue (or in the prologue); stores may still be in flight -> no counted wait.
+                }
+                PP_BARRIER();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < 2; ++nj)
+                            acc[mh * 4 + mi][nh * 2 + nj] = T::mfma16(bf[nh][nj][ks], af[mi][ks], acc[mh * 4 + mi][nh * 2 + nj]);
+                __builtin_amdgcn_s_setprio(0);
+                PP_BARRIER();
+            }
+        }
+        if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA for the next tile has landed
+        if (cur.m0 + BM <= g.M) epilogue_wave<T, EPI, 8, 4, true>(g, acc, cur.m0 + grp * 128 + (lane & 15), cur.n0 + wn * 64 + 8 * (lane >> 4));
+        else epilogue_wave<T, EPI, 8, 4, false>(g, acc, cur.m0 + grp * 128 + (lane & 15), cur.n0 + wn * 64 + 8 * (lane >> 4));
+        if (!has_next) break;
+        cur = nxt;
+        L = Ln;
+        gk += nk;
+    }
+}
+
+static int g_num_cu = 0;
+template <typename T, int EPI, int KTAG>
+static int launch_ppp_k(const GemmArgs& g, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 + 256) * 64 * 2;
+    auto kern = gemm_ppp_kernel<T, EPI, KTAG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("gemm_ppp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    if (g_num_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { slime_set_error("gemm_ppp: device query failed"); return SLIME_ELAUNCH; }
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int ntiles = ((g.M + 255) / 256) * (g.N / 256);
+    int grid = ntiles < g_num_cu ? ntiles : (g_num_cu / 8) * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, g);
+    SLIME_CHECK_LAUNCH("gemm_ppp");
+    return SLIME_OK;
+}
+template <typename T, int EPI>
+static int launch_ppp(const GemmArgs& g, hipStream_t stream) {
+    return g.K >= 2048 ? launch_ppp_k<T, EPI, 1>(g, stream) : launch_ppp_k<T, EPI, 0>(g, stream);
+}
+
+static int g_ablation = 0;
+static int g_stagger = 0;
+static unsigned long long* g_dbg = nullptr;
+extern "C" void slime_gemm_set_debug(void* p) { g_dbg = (unsigned long long*)p; }
+extern "C" void slime_gemm_set_ablation(int a) { g_ablation = a; }
+extern "C" void slime_gemm_set_stagger(int s) { g_stagger = s; }
+
+template <typename T, int EPI, int KTAG, int ABL>
 static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int LDS = 2 * (256 + 256) * 64 * 2;
-    auto kern = gemm_pp_kernel<T, EPI, KTAG>;
+    auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -422,7 +731,18 @@ static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
 
 template <typename T, int EPI>
 static int launch_pp(const GemmArgs& g, hipStream_t stream) {
-    return g.K >= 2048 ? launch_pp_k<T, EPI, 1>(g, stream) : launch_pp_k<T, EPI, 0>(g, stream);
+    if constexpr (EPI == SLIME_EPI_BIAS_T && T::id == SLIME_BF16) {     // ablation builds: one epilogue only
+        switch (g_ablation) {
+            case 1: return launch_pp_k<T, EPI, 0, 1>(g, stream);
+            case 2: return launch_pp_k<T, EPI, 0, 2>(g, stream);
+            case 3: return launch_pp_k<T, EPI, 0, 3>(g, stream);
+            case 4: return launch_pp_k<T, EPI, 0, 4>(g, stream);
+            case 7: return launch_pp_k<T, EPI, 0, 7>(g, stream);
+            case 8: return launch_pp_k<T, EPI, 0, 8>(g, stream);
+            default: break;
+        }
+    }
+    return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0>(g, stream) : launch_pp_k<T, EPI, 0, 0>(g, stream);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
@@ -447,7 +767,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
 // covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
 // running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256, 2 = 256x128, 3 = 128x128, 4 = 256x256 ping-pong
+static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256, 2 = 256x128, 3 = 128x128, 4 = 256x256 ping-pong, 5 = persistent ping-pong
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
@@ -456,7 +776,10 @@ template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
     if (tile == 0) tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;   // ping-pong 256x256, else 128x128
-    if ((tile == 1 || tile == 4) && g.N % 256 != 0) tile = 3;
+    if ((tile == 1 || tile == 4 || tile == 5) && g.N % 256 != 0) tile = 3;
+    if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
+    if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
+    if (tile == 5) return launch_ppp<T, EPI>(g, stream);
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (g_sched == 0) {
         switch (tile) {
@@ -494,7 +817,7 @@ extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bi
     SLIME_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm: bad leading dims lda=%d ldc=%d", lda, ldc);
     SLIME_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) &&
                   (!bias || (uintptr_t)bias % 16 == 0), "gemm: pointers must be 16-byte aligned");
-    GemmArgs g{(const char*)A, (const char*)B, bias, C, lda, ldc, M, N, K};
+    GemmArgs g{(const char*)A, (const char*)B, bias, C, lda, ldc, M, N, K, g_stagger, g_dbg};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SLIME_BF16) return launch_T<BF16>(g, epilogue, s);
     if (dtype == SLIME_F16) return launch_T<F16>(g, epilogue, s);
