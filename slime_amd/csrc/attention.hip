@@ -27,11 +27,34 @@ struct AttnArgs {
     const char* v; long v_bs, v_rs;
     char* o; long o_bs, o_rs;
     int heads, n_q, n_kv, sb_per_wg;
+    unsigned long long* dbg;      // diagnostic: 4 s_memtime stamps per wave (NULL in production)
 };
 
 template <int DH> __device__ __forceinline__ int v_swizzle(int row) {
     if constexpr (DH == 64) return ((row >> 1) & 1) | (((row >> 2) & 1) << 3);
     else return (row & 1) | (((row >> 1) & 3) << 3);
+}
+
+// max over the four 16-lane rows of a wave (lanes l, l+16, l+32, l+48), result in every row.
+// v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the second,
+// v_permlane32_swap the upper half of the first with the lower half of the second: with both operands
+// equal to x the two results hold the two partners of every lane.  Pure VALU -- a __shfl_xor would be a
+// ds_bpermute plus an LDS round trip (10 dependent ones per kv step here).
+__device__ __forceinline__ float rows_allmax(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_allsum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 __device__ __forceinline__ u32x2 lds_read_tr16(const char* p) {
@@ -52,6 +75,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
     char* Vlds = smem + KC * RB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int g = lane >> 4, li = lane & 15;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0;
+    if (a.dbg) t0 = __builtin_amdgcn_s_memtime();
 
     const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
     const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
@@ -126,6 +151,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
             }
         }
         __syncthreads();
+        if (a.dbg && kv0 == 0) t1 = __builtin_amdgcn_s_memtime();
 
         if constexpr (NSUB > 0) {
             const int rows = min(KC, a.n_kv - kv0);
@@ -155,50 +181,52 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
                             for (int s = 0; s < NSUB; ++s) if (dead) sc[s][t][r] = -INFINITY;
                         }
                 }
-                // ---- online softmax (lane-local: one q column per lane) ---------------------------
-                u32x4 pf[NSUB];
+                // ---- V^T fragments of this step (hardware transpose reads), shared by all sub-blocks ------
+                u32x4 vf[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const u32x2 v0 = lds_read_tr16(vp + voff[dt]);
+                    const u32x2 v1 = lds_read_tr16(vp + 16 * RB + voff[dt]);
+                    vf[dt] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                }
+                // ---- per sub-block: online softmax (lane-local: one q column per lane), then O^T += V^T P^T.
+                // Sub-block-major order lets the PV MFMAs of sub-block s run under the softmax VALU work of
+                // sub-block s+1 (separate pipes).
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s) {
                     float mx = fmaxf(fmaxf(fmaxf(sc[s][0][0], sc[s][0][1]), fmaxf(sc[s][0][2], sc[s][0][3])),
                                      fmaxf(fmaxf(sc[s][1][0], sc[s][1][1]), fmaxf(sc[s][1][2], sc[s][1][3])));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    mx = rows_allmax(mx);
                     const float m_new = fmaxf(m_run[s], mx);
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);
-                    const float mneg = -m_new * LOG2E;
+                    if (__builtin_amdgcn_ballot_w64(m_new != m_run[s]) != 0) {     // wave-uniform: some row's max moved
+                        const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);
+                        l_run[s] *= alpha;
+#pragma unroll
+                        for (int d = 0; d < DT; ++d) o[s][d] *= alpha;
+                        m_run[s] = m_new;
+                    }
+                    const float mneg = -m_run[s] * LOG2E;
                     float p[8];
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[s][t][r], LOG2E, mneg));
-                    l_run[s] = l_run[s] * alpha + ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-                    m_run[s] = m_new;
+                    l_run[s] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    const u32x4 pf = pack8<T>(p);
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) o[s][d] *= alpha;
-                    pf[s] = pack8<T>(p);
-                }
-                // ---- O^T += V^T P^T ----------------------------------------------------------------
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const u32x2 v0 = lds_read_tr16(vp + voff[dt]);
-                    const u32x2 v1 = lds_read_tr16(vp + 16 * RB + voff[dt]);
-                    const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-#pragma unroll
-                    for (int s = 0; s < NSUB; ++s) o[s][dt] = T::mfma16(vf, pf[s], o[s][dt]);
+                    for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
                 }
             }
         }
     }
 
+    if (a.dbg) t2 = __builtin_amdgcn_s_memtime();
     // ---- finalize: 1/l, 16-B stores of 8 consecutive d per lane ---------------------------------
     if constexpr (NSUB > 0) {
         char* obase = a.o + ((size_t)b * a.o_bs + (size_t)h * DH) * 2;
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            float l = l_run[s];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-            const float inv = 1.0f / l;
+            const float inv = 1.0f / rows_allsum(l_run[s]);
             const int qr = (sb0 + s) * 16 + li;
             if (qr < a.n_q) {
 #pragma unroll
@@ -209,6 +237,11 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
                 }
             }
         }
+    }
+    if (a.dbg && lane == 0) {
+        const int wv = tid >> 6;
+        unsigned long long* d = a.dbg + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (NW * 4) + wv * 4;
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -257,6 +290,9 @@ static int launch_attn(const AttnArgs& a0, int batch, hipStream_t stream) {
     return SLIME_OK;
 }
 
+static unsigned long long* g_attn_dbg = nullptr;
+extern "C" void slime_attention_set_debug(void* p) { g_attn_dbg = (unsigned long long*)p; }
+
 extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
                                const void* v, long v_bs, long v_rs, void* o, long o_bs, long o_rs,
                                int batch, int heads, int head_dim, int n_q, int n_kv, int dtype, void* stream) {
@@ -268,13 +304,13 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
     SLIME_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: pointers must be 16-byte aligned");
     SLIME_REQUIRE(batch <= 65535, "attention: batch %d exceeds grid.y", batch);
     AttnArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs,
-               (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0};
+               (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg};
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64) {
         // K+V resident up to 608 rows (CLIP S = 577); longer sequences stream in 608-row chunks.
         if (dtype == SLIME_F16) return launch_attn<F16, 64, 608, 8, 5>(a, batch, s);
         return launch_attn<BF16, 64, 608, 8, 5>(a, batch, s);
     }
-    if (dtype == SLIME_F16) return launch_attn<F16, 128, 288, 6, 3>(a, batch, s);
-    return launch_attn<BF16, 128, 288, 6, 3>(a, batch, s);
+    if (dtype == SLIME_F16) return launch_attn<F16, 128, 288, 8, 2>(a, batch, s);
+    return launch_attn<BF16, 128, 288, 8, 2>(a, batch, s);
 }

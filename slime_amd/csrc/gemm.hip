@@ -28,6 +28,19 @@ struct GemmArgs {
     unsigned long long* dbg;   // ABL & 8 builds only: 4 s_memtime stamps per workgroup
 };
 
+// erf-form GELU 0.5 x (1 + erf(x / sqrt 2)).  The device-library erff is a large branchy routine (it
+// put 1.2 KB of scratch into this epilogue and ran the projector GEMM at 114 TF/s); this is the
+// branch-free Abramowitz-Stegun 7.1.26 form, |erf error| <= 1.5e-7 absolute -- two orders below the
+// rounding of the 16-bit output -- with one v_rcp and one v_exp.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float tail = poly * __expf(-z * z);                       // 1 - erf(|x|/sqrt2)
+    const float one_plus_erf = x >= 0.f ? 2.0f - tail : tail;       // 1 + erf(x/sqrt2)
+    return 0.5f * x * one_plus_erf;
+}
+
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
@@ -111,9 +124,9 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                     if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {          // x*sigmoid(1.702x)
                         a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
                         b = b * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * b));
-                    } else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) {        // exact GELU
-                        a = 0.5f * a * (1.0f + erff(a * 0.70710678118654752440f));
-                        b = 0.5f * b * (1.0f + erff(b * 0.70710678118654752440f));
+                    } else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) {        // erf GELU (nn.GELU())
+                        a = gelu_erf(a);
+                        b = gelu_erf(b);
                     }
                     acc[i][2 * p][j] = a; acc[i][2 * p + 1][j] = b;
                 }
