@@ -87,6 +87,8 @@ _SIGNATURES = {
     "slime_gemm_set_stagger": (None, [c_int]),
     "slime_gemm_set_debug": (None, [c_void_p]),
     "slime_attention_set_debug": (None, [c_void_p]),
+    "slime_attention_set_variant": (None, [c_int]),
+    "slime_attention_set_ablation": (None, [c_int]),
 }
 
 _lib = None

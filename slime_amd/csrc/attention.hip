@@ -28,6 +28,7 @@ struct AttnArgs {
     char* o; long o_bs, o_rs;
     int heads, n_q, n_kv, sb_per_wg;
     unsigned long long* dbg;      // diagnostic: 4 s_memtime stamps per wave (NULL in production)
+    int abl;                      // diagnostic timing ablations of attn64 (0 in production): 1 = no softmax VALU, 2 = no MFMA
 };
 
 template <int DH> __device__ __forceinline__ int v_swizzle(int row) {
@@ -256,6 +257,9 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(AttnArgs a) {
     const int base = nsb / NW, rem = nsb % NW;
     const int cnt = base + (wave < rem ? 1 : 0);
     const int sb0 = wg_sb0 + wave * base + min(wave, rem);
+    // The second-dispatched half of a workgroup loses VALU arbitration to the older half on every SIMD
+    // (measured: 70-81k vs 52k compute cycles per wave); one static priority bump evens them out.
+    if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     switch (cnt) {
         case 0: attn_body<T, DH, KC, NW, 0>(a, smem, b, h, sb0); break;
         case 1: attn_body<T, DH, KC, NW, 1>(a, smem, b, h, sb0); break;
@@ -290,7 +294,294 @@ static int launch_attn(const AttnArgs& a0, int batch, hipStream_t stream) {
     return SLIME_OK;
 }
 
+
+// ================================================================================================
+// attn64_kernel: the CLIP self-attention shape (head_dim 64, n_kv <= 608 so K and V of one head are
+// LDS resident), software pipelined.
+//
+// Stamps of the generic kernel above showed 17k of ~95k cycles per workgroup in register-staged K/V
+// loading and ~390 cycles per (16-query sub-block x 32-kv step) against 128 of MFMA: within a wave the
+// stream was [QK MFMAs][softmax VALU][PV MFMAs], and issue is in order, so nothing overlapped.  Here:
+//   * K/V come in by LDS-DMA (no VGPR round trip, no ds_write pass), in two halves: kv rows 0..319 are
+//     waited for, rows 320..607 land under the first ten steps.  K is 16-B-chunk XOR-swizzled through
+//     the per-lane source address (conflict-free ds_read_b128); V can only be chunk-swizzled by a DMA
+//     (key = 64-B half flip on (row>>1)&1), which leaves the transpose reads 2-way conflicting -- 8 reads
+//     per 24 MFMAs, irrelevant;  rows >= n_kv are clamped copies of the last row (masked later).
+//   * score tiles are double buffered: QK(step+1) MFMAs are issued together with softmax(step) VALU work
+//     and PV(step) MFMAs, so the matrix pipe runs under the exp/max/sum stream of the same wave.
+//   * 3 sub-blocks per wave and a 2-way split of the 37 query sub-blocks: 2 workgroups per (crop, head),
+//     640 workgroups at 20 crops instead of 320 (1.25 rounds of 256 CUs).
+// ================================================================================================
+// Fragment reads of attn64 go through inline asm: with LDS-DMA in flight hipcc guards every compiler-
+// visible ds_read that may alias a DMA destination with s_waitcnt vmcnt(0), which would drain the second
+// K/V half before the first MFMA.  The DMA/barrier ordering is explicit in attn64_body; consumers are
+// ordered behind these reads by lgkm_wait_*(), which name the destination registers as "+v".
+__device__ __forceinline__ u32x4 lds_b128_asm(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+__device__ __forceinline__ u32x2 lds_tr16_asm(unsigned addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    return r;
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
+}
+
+template <typename T, int NSUB>
+__device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
+    constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608, NW = 8;
+    constexpr int ROWS1 = 320;                             // first DMA half (10 steps)
+    constexpr float LOG2E = 1.4426950408889634f;
+    char* Klds = smem;
+    char* Vlds = smem + KC * RB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+
+    // ---- Q fragments first (ordinary loads must be retired before any LDS-DMA is in flight) --------
+    u32x4 qf[NSUB > 0 ? NSUB : 1][KS];
+    if constexpr (NSUB > 0) {
+        const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[s][ks] = *reinterpret_cast<const u32x4*>(qbase + ((size_t)qr * a.q_rs + ks * 32 + g * 8) * 2);
+        }
+        // make the compiler retire the Q loads HERE (an empty asm that "uses" them): otherwise it waits
+        // vmcnt(0) at their first real use, i.e. with the K/V DMA in flight, draining both halves.
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[s][ks]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- K/V LDS-DMA: one wave instruction = 8 rows x 128 B; pieces dealt round-robin to the 8 waves ----
+    {
+        const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
+        const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
+        const int lrow = lane >> 3, cpos = lane & 7;
+        const int kchunk = cpos ^ lrow;                      // K: chunk ^ (row & 7)
+        const int vchunk = cpos ^ (((lrow >> 1) & 1) << 2);  // V: 64-B half flip on (row >> 1) & 1
+        auto dma_rows = [&](int piece) {                     // piece = 8-row group index
+            const int row = min(piece * 8 + lrow, a.n_kv - 1);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
+                                             LDS_PTR(Klds + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(vbase + ((size_t)row * a.v_rs) * 2 + vchunk * 16),
+                                             LDS_PTR(Vlds + piece * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int i = 0; i < ROWS1 / 8 / NW; ++i) dma_rows(i * NW + wave);                  // 5 x 2 per wave
+#pragma unroll
+        for (int i = 0; i < (KC - ROWS1) / 8 / NW; ++i) dma_rows(ROWS1 / 8 + i * NW + wave);   // 4 x 2 (+ tail below)
+        if (wave < ((KC - ROWS1) / 8) % NW) dma_rows(ROWS1 / 8 + ((KC - ROWS1) / 8 / NW) * NW + wave);
+    }
+    // second-half pieces still in flight per wave: 2 * (4 or 5)
+    if (wave < ((KC - ROWS1) / 8) % NW) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int steps = (a.n_kv + 31) >> 5;
+    if constexpr (NSUB == 0) {
+        if (steps > ROWS1 / 32) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_barrier" ::: "memory");
+        }
+        return;
+    } else {
+        // o[s][0..3]: O^T d-tiles; o[s][4]: the row-sum tile (A operand = a constant fragment whose row 0 is
+        // all ones, so the matrix pipe accumulates sum_kv P[q][kv] in row 0 -- the VALU is the bound here).
+        f32x4 o[NSUB][DT + 1];
+        float m_run[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            m_run[s] = -INFINITY;
+#pragma unroll
+            for (int d = 0; d <= DT; ++d) o[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned one2 = T::pack2(1.0f, 1.0f);
+        const unsigned onew = (li == 0) ? one2 : 0u;
+        const u32x4 ones = {onew, onew, onew, onew};
+        int koff[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) koff[ks] = li * RB + (((ks * 4 + g) ^ (lane & 7)) << 4);
+        int voff[DT];
+        {
+            const int vrow = 4 * g + (li >> 2);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                voff[dt] = vrow * RB + (((4 * (dt >> 1) + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4) + (dt & 1) * 8;
+        }
+        const unsigned kbase_lds = lds_addr(Klds), vbase_lds = lds_addr(Vlds);
+
+        auto qk = [&](int st, f32x4 (&sc)[NSUB][2]) {
+            const unsigned kp = kbase_lds + st * 32 * RB;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) { sc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            u32x4 kf[2][KS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = lds_b128_asm(kp + t * 16 * RB + koff[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], sc[s][t]);
+        };
+        // One kv step for all sub-blocks, branch free (one basic block: the scheduler may interleave the
+        // independent sub-block chains and the MFMAs with the VALU stream).
+        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], bool masked) {
+            const unsigned vp = vbase_lds + st * 32 * RB;
+            u32x2 v0[DT], v1[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                v0[dt] = lds_tr16_asm(vp + voff[dt]);
+                v1[dt] = lds_tr16_asm(vp + 16 * RB + voff[dt]);
+            }
+            if (masked) {                                    // ragged tail: kv >= n_kv -> -inf (selects, no branch)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dead = st * 32 + t * 16 + 4 * g + r >= a.n_kv;
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) sc[s][t][r] = dead ? -INFINITY : sc[s][t][r];
+                    }
+            }
+            float alpha[NSUB], mneg[NSUB];
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                // lane-local max of the 8 scores and the (row-uniform) running max, then across the 4 rows
+                float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][3]), m_run[s]);
+                const float m_new = rows_allmax(mx);
+                alpha[s] = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);     // exp2(-inf) = 0 on the first step
+                mneg[s] = -m_new * LOG2E;
+                m_run[s] = m_new;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
+                                                   "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
+            u32x4 vf[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = u32x4{v0[dt][0], v0[dt][1], v1[dt][0], v1[dt][1]};
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+#pragma unroll
+                for (int d = 0; d <= DT; ++d) o[s][d] *= alpha[s];
+                float p[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[s][t][r], LOG2E, mneg[s]));
+                const u32x4 pf = pack8<T>(p);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
+                o[s][DT] = T::mfma16(ones, pf, o[s][DT]);
+            }
+        };
+        auto second_half_ready = [&](int st_next) {          // before the first read of kv rows >= ROWS1
+            if (st_next == ROWS1 / 32) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+
+        f32x4 sA[NSUB][2], sB[NSUB][2];
+        const bool ragged = (a.n_kv & 31) != 0;
+        qk(0, sA);
+        int st = 0;
+        for (; st + 2 < steps; st += 2) {                    // neither st nor st+1 is the last step
+            second_half_ready(st + 1);
+            qk(st + 1, sB);                                  // next step's scores under this step's softmax
+            softmax_pv(st, sA, false);
+            second_half_ready(st + 2);
+            qk(st + 2, sA);
+            softmax_pv(st + 1, sB, false);
+        }
+        if (st + 2 == steps) {
+            second_half_ready(st + 1);
+            qk(st + 1, sB);
+            softmax_pv(st, sA, false);
+            softmax_pv(st + 1, sB, ragged);
+        } else {
+            softmax_pv(st, sA, ragged);
+        }
+
+        char* obase = a.o + ((size_t)b * a.o_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const float inv = 1.0f / rows_allsum(o[s][DT][0]);    // row 0 of the sum tile lives in quad 0, r = 0
+            const int qr = (sb0 + s) * 16 + li;
+            if (qr < a.n_q) {
+#pragma unroll
+                for (int p = 0; p < DT / 2; ++p) {
+                    float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
+                                  o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
+                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_sb = (a.n_q + 15) >> 4;
+    const int wg_sb0 = blockIdx.z * a.sb_per_wg;
+    const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);
+    const int base = nsb / NW, rem = nsb % NW;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int sb0 = wg_sb0 + wave * base + min(wave, rem);
+    switch (cnt) {
+        case 0: attn64_body<T, 0>(a, smem, b, h, sb0); break;
+        case 1: attn64_body<T, 1>(a, smem, b, h, sb0); break;
+        case 2: attn64_body<T, 2>(a, smem, b, h, sb0); break;
+        default: attn64_body<T, 3>(a, smem, b, h, sb0); break;
+    }
+}
+
+template <typename T>
+static int launch_attn64(const AttnArgs& a0, int batch, hipStream_t stream) {
+    AttnArgs a = a0;
+    constexpr int LDS = 2 * 608 * 128;
+    auto kern = attn64_kernel<T>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    const int total_sb = (a.n_q + 15) / 16;
+    const int qsplit = (total_sb + 23) / 24;                  // <= 3 sub-blocks per wave, 8 waves
+    a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
+    hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(512), LDS, stream, a);
+    SLIME_CHECK_LAUNCH("attention64");
+    return SLIME_OK;
+}
+
 static unsigned long long* g_attn_dbg = nullptr;
+static int g_attn_abl = 0;
+extern "C" void slime_attention_set_ablation(int v) { g_attn_abl = v; }
+static int g_attn_variant = 0;      // test/bench hook: 1 = force the generic kernel
+extern "C" void slime_attention_set_variant(int v) { g_attn_variant = v; }
 extern "C" void slime_attention_set_debug(void* p) { g_attn_dbg = (unsigned long long*)p; }
 
 extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
@@ -304,8 +595,13 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
     SLIME_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: pointers must be 16-byte aligned");
     SLIME_REQUIRE(batch <= 65535, "attention: batch %d exceeds grid.y", batch);
     AttnArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs,
-               (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg};
+               (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg, g_attn_abl};
     hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 0 && !g_attn_dbg) {
+        // CLIP shape: software-pipelined kernel (the DMA split assumes the second half is non-empty)
+        if (dtype == SLIME_F16) return launch_attn64<F16>(a, batch, s);
+        return launch_attn64<BF16>(a, batch, s);
+    }
     if (head_dim == 64) {
         // K+V resident up to 608 rows (CLIP S = 577); longer sequences stream in 608-row chunks.
         if (dtype == SLIME_F16) return launch_attn<F16, 64, 608, 8, 5>(a, batch, s);

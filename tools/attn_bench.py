@@ -15,7 +15,11 @@ for B in (16, 20, 40):
     qkv = torch.randn(B, 577, 3072, device=dev).to(dt); qkv[..., :1024] *= 0.125
     q, k, v = qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:]
     t = timeit(lambda: ops.attention(q, k, v, 16, 64))
-    print(f"attention vit B={B}: {t*1e3:.3f} ms {4.0*B*16*577*577*64/t/1e12:.1f} TF/s", flush=True)
+    print(f"attention vit B={B} attn64    : {t*1e3:.3f} ms {4.0*B*16*577*577*64/t/1e12:.1f} TF/s", flush=True)
+    lib.slime_attention_set_variant(1)
+    t = timeit(lambda: ops.attention(q, k, v, 16, 64))
+    print(f"attention vit B={B} generic   : {t*1e3:.3f} ms {4.0*B*16*577*577*64/t/1e12:.1f} TF/s", flush=True)
+    lib.slime_attention_set_variant(0)
 for B, nq in ((32, 144), (8, 576)):
     qq = (torch.randn(1, nq, 1024, device=dev) * 0.088).to(dt); kk = torch.randn(B, 576, 1024, device=dev).to(dt); vv = torch.randn(B, 576, 1024, device=dev).to(dt)
     t = timeit(lambda: ops.attention(qq, kk, vv, 8, 128))
