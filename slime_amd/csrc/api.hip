@@ -24,16 +24,6 @@ extern "C" int slime_abi_version(void) { return SLIME_ABI_VERSION; }
     } while (0)
 
 namespace {
-// bump allocator over the caller's workspace
-struct Arena {
-    char* base; size_t size; size_t off;
-    explicit Arena(void* p, size_t n) : base((char*)p), size(n), off(0) {}
-    void* take(size_t bytes) {
-        const size_t o = align_up(off, 256);
-        off = o + bytes;
-        return (base && off <= size) ? base + o : nullptr;
-    }
-};
 static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
 }  // namespace
 

@@ -719,6 +719,291 @@ static int launch_ppp(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_ppp_k<T, EPI, 1>(g, stream) : launch_ppp_k<T, EPI, 0>(g, stream);
 }
 
+
+// ================================================================================================
+// 32x32x16 MFMA variant (measured alternative, not the default): 1024 vs ~915 flop/cycle/SIMD of issue
+// bound, half the matrix instructions and operand reads per flop.  A first version with the 4-phase table
+// of gemm_pp_kernel (8 MFMAs on 2 accumulators per M section) was bound by the 64-cycle dependent latency
+// (-15 %); the 2-phase kernel below removes that and still trails the 16x16 kernel by ~10 % (1075 vs
+// 1230 TF/s at K = 4096): its L sections (16 fragment reads drained before the barrier) are long.
+//   * fragments: a lane feeds row (lane & 31), k = 8*(lane >> 5) .. +7 of a 16-deep k-step
+//     -> ds_read_b128 of chunk 2*ks + (lane >> 5); the 16-lane ds_read_b128 groups then touch 16
+//     different rows with one chunk index, so the swizzle key is (row >> 1) & 7 (8 distinct keys per row
+//     parity inside every group) instead of row & 7;
+//   * D layout: col = lane & 31 (the X row m), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (the W row n);
+//     W rows are permuted inside each 32-row tile while staging so that D row index i maps to
+//     n = 16*(lane>>5) + r: a lane owns 16 consecutive output columns of one row.
+// ================================================================================================
+template <typename T, int EPI, bool FULL>
+__device__ __forceinline__ void epilogue_wave32(const GemmArgs& g, f32x16 (&acc)[4][2], const int row_base, const int col_base) {
+    // row_base: m0 + grp*128 + (lane & 31); col_base: n0 + wn*64 + 16*(lane >> 5); tile (mi, nj) adds (32 mi, 32 nj)
+    float bias[2][16];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + col_base + 32 * nj + 4 * v4);
+            bias[nj][4 * v4 + 0] = bv.x; bias[nj][4 * v4 + 1] = bv.y; bias[nj][4 * v4 + 2] = bv.z; bias[nj][4 * v4 + 3] = bv.w;
+        }
+    auto in_range = [&](int row) { return FULL || row < g.M; };
+    if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32) {
+        float* C = reinterpret_cast<float*>(g.C);
+        float4 hb[2][2][4];                                   // [buffer][nj][v4]: one 32-row step ahead
+        auto load_step = [&](int mi, int buf) {
+            int row = row_base + mi * 32;
+            if constexpr (!FULL) row = min(row, g.M - 1);
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4)
+                    hb[buf][nj][v4] = *reinterpret_cast<const float4*>(C + (size_t)row * g.ldc + col_base + 32 * nj + 4 * v4);
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            if (mi + 1 < 4) load_step(mi + 1, (mi + 1) & 1);
+            const int row = row_base + mi * 32;
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) {
+#pragma unroll
+                for (int v4 = 0; v4 < 4; ++v4) {
+                    const float4 hv = hb[mi & 1][nj][v4];
+                    acc[mi][nj][4 * v4 + 0] += bias[nj][4 * v4 + 0] + hv.x; acc[mi][nj][4 * v4 + 1] += bias[nj][4 * v4 + 1] + hv.y;
+                    acc[mi][nj][4 * v4 + 2] += bias[nj][4 * v4 + 2] + hv.z; acc[mi][nj][4 * v4 + 3] += bias[nj][4 * v4 + 3] + hv.w;
+                }
+                if (in_range(row)) {
+                    float* o = C + (size_t)row * g.ldc + col_base + 32 * nj;
+#pragma unroll
+                    for (int v4 = 0; v4 < 4; ++v4)
+                        *reinterpret_cast<float4*>(o + 4 * v4) = make_float4(acc[mi][nj][4 * v4], acc[mi][nj][4 * v4 + 1], acc[mi][nj][4 * v4 + 2], acc[mi][nj][4 * v4 + 3]);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float a = acc[mi][nj][r] + bias[nj][r];
+                    if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
+                    else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) a = gelu_erf(a);
+                    acc[mi][nj][r] = a;
+                }
+        if constexpr (EpiOutIsT<EPI>::value) {
+            u32x4 packed[4][2][2];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int hv = 0; hv < 2; ++hv)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) packed[mi][nj][hv][w] = T::pack2(acc[mi][nj][8 * hv + 2 * w], acc[mi][nj][8 * hv + 2 * w + 1]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = row_base + mi * 32;
+                if (in_range(row)) {
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) {
+                        char* o = reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * nj) * 2;
+                        *reinterpret_cast<u32x4*>(o) = packed[mi][nj][0];
+                        *reinterpret_cast<u32x4*>(o + 16) = packed[mi][nj][1];
+                    }
+                }
+            }
+        } else {
+            float* C = reinterpret_cast<float*>(g.C);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = row_base + mi * 32;
+                if (in_range(row)) {
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) {
+                        float* o = C + (size_t)row * g.ldc + col_base + 32 * nj;
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; ++v4)
+                            *reinterpret_cast<float4*>(o + 4 * v4) = make_float4(acc[mi][nj][4 * v4], acc[mi][nj][4 * v4 + 1], acc[mi][nj][4 * v4 + 2], acc[mi][nj][4 * v4 + 3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// gemm_pp32b_kernel: 32x32x16 MFMA, TWO phases per k-tile.
+// The 4-phase 32x32 kernel above accumulates 8 MFMAs on 2 accumulators per M section and is bound by the
+// 64-cycle dependent latency of v_mfma_f32_32x32x16 (measured 15 % slower than the 16x16 kernel).  Here a
+// phase is a 64x64 half of the wave tile: 4 independent accumulators x 4 k-steps = 16 MFMAs (~512 cycles),
+// so the matrix pipe streams at its issue rate and there are half as many barriers per k-tile.
+//
+// Slots: tile t phase p -- group 0: L at 4t+2p, M at 4t+2p+1; group 1 one slot later.  Every L section
+// ends with lgkmcnt(0) BEFORE its barrier, so a region is free for refill one slot after its last reader's
+// L section.  Readers: A(own half, rows 0..63) and all of B in L0, A(rows 64..127) in L1.  Refill of the
+// stage buffer for tile t+2 (4 pieces per wave per section):
+//     L1(t)   : this group's half of the B tile of t+2      (B last read by group 1 in slot 4t+1)
+//     L0(t+1) : this group's 128 A rows of t+2              (last read in L1(t), slots 4t+2 / 4t+3)
+// and every L1 section retires all but its own 4 newest pieces (vmcnt(4)) one barrier or more before
+// their first reader (L0(t+2)); a piece is in flight for >= 2 slots (~1100 cycles).
+// ================================================================================================
+template <typename T, int EPI, int KTAG>
+__global__ void __launch_bounds__(512) gemm_pp32b_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int GROUP_M = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int in_group = GROUP_M * tiles_n;
+    const int first_m = (pid / in_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % in_group) % gsz;
+    const int tn = (pid % in_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- LDS-DMA pieces: kind 0 = 4 pieces of this group's A half (16 pieces, 4 per wave),
+    //                      kind 1 = 4 pieces of this group's half of the B tile (rows grp*128 .. +127) ----
+    const char* src[2][4];
+    int dst[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int piece = wn * 4 + j;                                   // 0..15: 8-row piece inside the 128-row half
+        {
+            const int row = grp * 128 + piece * 8;
+            const int key = ((row + lrow) >> 1) & 7;
+            const int gm = min(m0 + row + lrow, g.M - 1);
+            src[0][j] = g.A + ((size_t)gm * g.lda) * 2 + ((cpos ^ key) << 4);
+            dst[0][j] = row * 128;
+        }
+        {
+            const int rho = grp * 128 + piece * 8 + lrow;               // LDS row of the B tile
+            const int key = (rho >> 1) & 7;
+            const int r32 = rho & 31;
+            const int nphys = (rho & ~31) + 16 * ((r32 >> 2) & 1) + 4 * (r32 >> 3) + (r32 & 3);
+            src[1][j] = g.B + ((size_t)(n0 + nphys) * g.K) * 2 + ((cpos ^ key) << 4);
+            dst[1][j] = A_BYTES + (grp * 128 + piece * 8) * 128;
+        }
+    }
+    auto issue = [&](int kind, int tile) {
+        char* base = smem + (tile & 1) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src[kind][j]), LDS_PTR(base + dst[kind][j]), 16, 0, 0);
+            src[kind][j] += BK * 2;
+        }
+    };
+
+    int a_off[4], b_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int sw = ((ks * 2 + lh) ^ ((lane >> 1) & 7)) << 4;
+        a_off[ks] = (grp * 128 + l31) * 128 + sw;
+        b_off[ks] = A_BYTES + (wn * 64 + l31) * 128 + sw;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    issue(0, 0); issue(1, 0);                                 // all of tile 0
+    if (nk > 1) {
+        issue(1, 1);                                          // B of tile 1 (an "L1(-1)" piece set); A(1) comes in L0(0)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();
+
+    u32x4 af[2][4], bf[2][4];
+    for (int t = 0; t < nk; ++t) {
+        const char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            // ---------------- L section ----------------
+            if (p == 0) {
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bf[nj][ks] = *reinterpret_cast<const u32x4*>(sb + b_off[ks] + nj * 32 * 128);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (p * 64 + mi * 32) * 128);
+            if (p == 0) {                                     // L0(t): this group's A rows of tile t+1
+                if (t + 1 < nk) issue(0, t + 1);
+            } else {                                          // L1(t): this group's B half of tile t+2; retire the rest
+                if (t + 2 < nk) { issue(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // the fragment reads must have LEFT the LDS before the other group may refill what they read
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[0][2]), "+v"(af[0][3]),
+                                                   "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[1][2]), "+v"(af[1][3]));
+            if (p == 0)
+                asm volatile("" : "+v"(bf[0][0]), "+v"(bf[0][1]), "+v"(bf[0][2]), "+v"(bf[0][3]),
+                                  "+v"(bf[1][0]), "+v"(bf[1][1]), "+v"(bf[1][2]), "+v"(bf[1][3]));
+            PP_BARRIER();
+            // ---------------- M section: 64 x 64 half, 4 accumulators x 4 k-steps ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        acc[p * 2 + mi][nj] = T::mfma32(bf[nj][ks], af[mi][ks], acc[p * 2 + mi][nj]);
+            __builtin_amdgcn_s_setprio(0);
+            PP_BARRIER();
+        }
+    }
+    if (grp == 0) PP_BARRIER();
+
+    if (m0 + BM <= g.M) epilogue_wave32<T, EPI, true>(g, acc, m0 + grp * 128 + l31, n0 + wn * 64 + 16 * lh);
+    else epilogue_wave32<T, EPI, false>(g, acc, m0 + grp * 128 + l31, n0 + wn * 64 + 16 * lh);
+}
+
+template <typename T, int EPI, int KTAG>
+static int launch_pp32b_k(const GemmArgs& g, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 + 256) * 64 * 2;
+    auto kern = gemm_pp32b_kernel<T, EPI, KTAG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("gemm_pp32b: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
+    SLIME_CHECK_LAUNCH("gemm_pp32b");
+    return SLIME_OK;
+}
+template <typename T, int EPI>
+static int launch_pp32b(const GemmArgs& g, hipStream_t stream) {
+    return g.K >= 2048 ? launch_pp32b_k<T, EPI, 1>(g, stream) : launch_pp32b_k<T, EPI, 0>(g, stream);
+}
+
 static int g_ablation = 0;
 static int g_stagger = 0;
 static unsigned long long* g_dbg = nullptr;
@@ -780,7 +1065,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
 // covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
 // running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256, 2 = 256x128, 3 = 128x128, 4 = 256x256 ping-pong, 5 = persistent ping-pong
+static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong (default), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
@@ -789,7 +1074,10 @@ template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
     if (tile == 0) tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;   // ping-pong 256x256, else 128x128
-    if ((tile == 1 || tile == 4 || tile == 5) && g.N % 256 != 0) tile = 3;
+    if (tile == 2) tile = 1;
+    if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
+    if (tile == 6) tile = 7;
+    if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
     if (tile == 5) return launch_ppp<T, EPI>(g, stream);
@@ -797,13 +1085,11 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (g_sched == 0) {
         switch (tile) {
             case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream);
-            case 2: return launch_cfg<T, 256, 128, 4, 2, EPI, 0>(g, stream);
             default: return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
         }
     }
     switch (tile) {
         case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
-        case 2: return launch_cfg<T, 256, 128, 4, 2, EPI, 1>(g, stream);
         default: return launch_cfg<T, 128, 128, 2, 2, EPI, 1>(g, stream);
     }
 }

@@ -122,8 +122,8 @@ def process_anyres_image_gpu(image: Image.Image, processor, grid_pinpoints, devi
     _parse_pinpoints(grid_pinpoints)
     thumb, canvas = anyres_canvas(image, processor)
     crop = processor.crop_size["height"]
-    t = torch.from_numpy(np.asarray(thumb.convert("RGB"))).to(device, non_blocking=True)
-    c = torch.from_numpy(np.asarray(canvas)).to(device, non_blocking=True)
+    t = torch.from_numpy(np.array(thumb.convert("RGB"))).to(device, non_blocking=True)
+    c = torch.from_numpy(np.array(canvas)).to(device, non_blocking=True)
     g = ops.tile_normalize(t, crop, processor.image_mean, processor.image_std, dtype)
     l = ops.tile_normalize(c, crop, processor.image_mean, processor.image_std, dtype)
     return torch.cat([g, l], dim=0)

@@ -18,9 +18,8 @@ The tower hands fp32 features to the adapter (the reference hands over fp16/bf16
 """
 from __future__ import annotations
 
-import math
 from abc import ABC, abstractmethod
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn
@@ -216,7 +215,8 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         if adapter_sd is not None:
             from ..weights import sub_state
             self.model.mm_projector.load_state_dict(sub_state(adapter_sd, "mm_projector."), strict=True)
-            self.model.sampler.load_state_dict(sub_state(adapter_sd, "sampler."), strict=True)
+            if len(self.model.sampler.state_dict()) > 0:          # IdentityMap (no sampler) has no parameters
+                self.model.sampler.load_state_dict(sub_state(adapter_sd, "sampler."), strict=True)
         return self
 
     @torch.no_grad()

@@ -203,3 +203,64 @@ def test_gpu_slicer_matches_pil_path(dev):
         out = M.process_anyres_image_gpu(img, proc, PIN, dev)
         assert out.shape == ref.shape
         assert torch.equal(out.cpu(), ref), (w, h)            # same fp32 arithmetic order as the HF processor
+
+
+def test_encode_images_flags_and_mask(dev):
+    """images_mask (collator-padded crops, train.py:903-926 / llava_arch.py:228-231), 'flat' merge,
+    use_global_only / use_local_only, and the branches without a sampler."""
+    from slime_amd import weights as W
+    from slime_amd.constants import IMAGE_TOKEN_INDEX
+    from oracle import slime_oracle as O
+    dtype = torch.bfloat16
+    torch.manual_seed(1)
+    embed = nn.Embedding(2000, 256).to(dev)
+    ids = torch.randint(3, 1900, (2, 10), device=dev)
+    ids[:, 2] = IMAGE_TOKEN_INDEX
+    am = torch.ones_like(ids)
+    # two images padded to 1 + 4 crops; image 0 really has 2 local crops, image 1 has 4
+    px = [W.synthetic_pixels(5, seed=70 + i) for i in range(2)]
+    images = torch.cat(px, 0).to(dev).to(dtype)
+    mask = torch.tensor([[1, 1, 1, 0, 0], [1, 1, 1, 1, 1]], device=dev)
+    sizes = [(336, 336), (672, 672)]
+    enc, tsd, asd = _tiny_encoder(dev, dtype, embed=embed)
+    feats, _ = enc.encode_images(images, input_ids=ids, split_sizes=[5, 5], attention_mask=am, images_mask=mask,
+                                 image_sizes=sizes)
+    text, tmask = enc.get_pure_text_embedding(ids, am)
+    for i, n_real in enumerate((2, 4)):
+        ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i][: 1 + n_real], sizes[i], text[i].float().cpu(),
+                             tmask[i].cpu())
+        out = feats[i][0].float().cpu()
+        assert rel_l2(out[:576], ref["global"]) < TOL[dtype] * 1.5
+        assert abs((out.shape[0] - 577) - ref["router_keep"].numel()) <= 2
+    # flat merge keeps crop-major order
+    enc_f, _, _ = _tiny_encoder(dev, dtype, embed=embed, mm_patch_merge_type="flat")
+    pairs = enc_f.encode_visual(images[:5], [5], [(672, 672)], merge="flat")
+    ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[0], (672, 672), merge="flat")
+    assert rel_l2(pairs[0][1].cpu(), ref["merged"]) < TOL[dtype] * 2
+    # use_global_only / use_local_only
+    enc_g, _, _ = _tiny_encoder(dev, dtype, embed=embed, use_global_only=True)
+    fg, _ = enc_g.encode_images(images[:5], input_ids=ids[:1], split_sizes=[5], attention_mask=am[:1], image_sizes=[(672, 672)])
+    assert fg[0].shape == (1, 576, 256)
+    enc_l, _, _ = _tiny_encoder(dev, dtype, embed=embed, use_local_only=True)
+    fl, _ = enc_l.encode_images(images[:5], input_ids=ids[:1], split_sizes=[5], attention_mask=am[:1], image_sizes=[(672, 672)])
+    assert fl[0].shape[0] == 1 and fl[0].shape[2] == 256 and 0 < fl[0].shape[1] <= 576
+    # no sampler: plain batch through the gated projector, and the split_sizes list branch
+    enc_n, _, _ = _tiny_encoder(dev, dtype, embed=embed, mm_resampler_type=None)
+    assert not enc_n.get_model().has_sampler
+    plain, _ = enc_n.encode_images(images[:3])
+    ref_plain = O.gated_block_forward(W.sub_state(asd, "mm_projector."), O.tower_forward(tsd, W.TINY, px[0][:3]), 1)
+    assert plain.shape == (3, 576, 256) and rel_l2(plain.float().cpu(), ref_plain) < TOL[dtype] * 2
+    lst, ss = enc_n.encode_images(images[:5], split_sizes=[2, 3])
+    assert ss == [2, 3] and [t.shape[0] for t in lst] == [2, 3]
+    assert rel_l2(torch.cat(lst).float().cpu()[:3], ref_plain) < TOL[dtype] * 2
+
+
+def test_tower_list_edge_cases(dev):
+    from slime_amd import weights as W
+    enc, _, _ = _tiny_encoder(dev, torch.bfloat16)
+    tower = enc.get_vision_tower()
+    assert tower([]) == []
+    one = tower([W.synthetic_pixels(1, seed=1)[0].to(dev)])
+    assert len(one) == 1 and one[0].shape == (1, 576, 128)
+    with pytest.raises(ValueError, match="doesn't match model"):
+        tower(torch.zeros(1, 3, 224, 224, device=dev))
