@@ -69,7 +69,7 @@ PROBE_KERNELS = {
     3: ("out_proj+residual", "gemm_pp_kernel<BF16, 4, 0, 0>", 1024, 1024),
     5: ("fc1+quick_gelu", "gemm_pp_kernel<BF16, 1, 0, 0>", 4096, 1024),
     6: ("fc2+residual", "gemm_pp_kernel<BF16, 4, 1, 0>", 1024, 4096),
-    2: ("attention", "attn_kernel<BF16, 64, 608, 8, 5>", 0, 0),
+    2: ("attention", "attn64_kernel<BF16>", 0, 0),
 }
 
 

@@ -84,7 +84,7 @@ _SIGNATURES = {
     "slime_gemm_force_tile": (None, [c_int]),
     "slime_gemm_set_sched": (None, [c_int]),
     "slime_gemm_set_ablation": (None, [c_int]),
-    "slime_gemm_set_stagger": (None, [c_int]),
+    "slime_gemm_set_group_m": (None, [c_int]),
     "slime_gemm_set_debug": (None, [c_void_p]),
     "slime_attention_set_debug": (None, [c_void_p]),
     "slime_attention_set_variant": (None, [c_int]),

@@ -335,6 +335,7 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
     constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608, NW = 8;
     constexpr int ROWS1 = 320;                             // first DMA half (10 steps)
     constexpr float LOG2E = 1.4426950408889634f;
+    constexpr float RESCALE_TH = 8.0f / LOG2E;
     char* Klds = smem;
     char* Vlds = smem + KC * RB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -397,7 +398,8 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
         return;
     } else {
         // o[s][0..3]: O^T d-tiles; o[s][4]: the row-sum tile (A operand = a constant fragment whose row 0 is
-        // all ones, so the matrix pipe accumulates sum_kv P[q][kv] in row 0 -- the VALU is the bound here).
+        // all ones, so the matrix pipe accumulates sum_kv P[q][kv] in row 0 -- the VALU is the bound here;
+        // measured: lane-local fp32 sums instead are 3 % slower).
         f32x4 o[NSUB][DT + 1];
         float m_run[NSUB];
 #pragma unroll
@@ -458,19 +460,34 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                         for (int s = 0; s < NSUB; ++s) sc[s][t][r] = dead ? -INFINITY : sc[s][t][r];
                     }
             }
-            float alpha[NSUB], mneg[NSUB];
+            // Lazy rescale: m_run is a REFERENCE max, refreshed only when some query of the wave sees a score
+            // more than 8 (log2 units) above it, so p = exp2(s - m_run) <= 256 -- harmless in fp32 sums and in
+            // 16-bit P (same relative precision) -- and the 20 multiplies + exp of the accumulator rescale
+            // leave the steady-state VALU stream (it fires in the first step or two of a sub-block).
+            float mc[NSUB];
+            bool need = false;
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
-                // lane-local max of the 8 scores and the (row-uniform) running max, then across the 4 rows
                 float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
-                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][3]), m_run[s]);
-                const float m_new = rows_allmax(mx);
-                alpha[s] = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);     // exp2(-inf) = 0 on the first step
-                mneg[s] = -m_new * LOG2E;
-                m_run[s] = m_new;
+                mx = __builtin_fmaxf(mx, sc[s][1][3]);
+                mc[s] = rows_allmax(mx);
+                need |= mc[s] > m_run[s] + RESCALE_TH;
             }
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {    // wave-uniform, rare
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) {
+                    const float m_new = __builtin_fmaxf(m_run[s], mc[s]);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);   // exp2(-inf) = 0 on the first step
+#pragma unroll
+                    for (int d = 0; d <= DT; ++d) o[s][d] *= alpha;
+                    m_run[s] = m_new;
+                }
+            }
+            float mneg[NSUB];
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) mneg[s] = -m_run[s] * LOG2E;
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
                                                    "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
             u32x4 vf[DT];
@@ -478,8 +495,6 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
             for (int dt = 0; dt < DT; ++dt) vf[dt] = u32x4{v0[dt][0], v0[dt][1], v1[dt][0], v1[dt][1]};
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
-#pragma unroll
-                for (int d = 0; d <= DT; ++d) o[s][d] *= alpha[s];
                 float p[8];
 #pragma unroll
                 for (int t = 0; t < 2; ++t)

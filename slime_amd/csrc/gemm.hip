@@ -24,7 +24,7 @@
 struct GemmArgs {
     const char* A; const char* B; const float* bias; void* C;
     int lda, ldc, M, N, K;
-    int stagger;      // first-round start stagger of the ping-pong kernel, in units of 64*16 cycles per step
+    int group_m;      // row tiles per L2 patch of the ping-pong kernel (0 = default 4)
     unsigned long long* dbg;   // ABL & 8 builds only: 4 s_memtime stamps per workgroup
 };
 
@@ -347,7 +347,6 @@ template <typename T, int EPI, int KTAG, int ABL = 0>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64;
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
-    constexpr int GROUP_M = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
@@ -357,6 +356,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 4;   // 4 x 8 tiles per XCD round (measured: 4 >= 2,8 > 16 > 46 by ~1-3 %)
     const int in_group = GROUP_M * tiles_n;
     const int group_id = pid / in_group;
     const int first_m = group_id * GROUP_M;
@@ -365,13 +365,6 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     const int tn = (pid % in_group) / gsz;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // De-synchronise the CUs: all workgroups of a round would otherwise run their HBM-bound prologue
-    // (112 KB in) and epilogue (128-256 KB out) phases at the same instant.  The first round starts
-    // staggered over 8 steps; later rounds inherit the skew (a CU takes its next workgroup when it is free).
-    if (g.stagger > 0 && blockIdx.x < 256) {
-        const int steps = (blockIdx.x >> 3) & 7;
-        for (int i = 0; i < steps * g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
     if constexpr ((ABL & 8) != 0) t_start = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1005,11 +998,11 @@ static int launch_pp32b(const GemmArgs& g, hipStream_t stream) {
 }
 
 static int g_ablation = 0;
-static int g_stagger = 0;
+static int g_group_m = 0;
 static unsigned long long* g_dbg = nullptr;
 extern "C" void slime_gemm_set_debug(void* p) { g_dbg = (unsigned long long*)p; }
 extern "C" void slime_gemm_set_ablation(int a) { g_ablation = a; }
-extern "C" void slime_gemm_set_stagger(int s) { g_stagger = s; }
+extern "C" void slime_gemm_set_group_m(int s) { g_group_m = s; }
 
 template <typename T, int EPI, int KTAG, int ABL>
 static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
@@ -1073,7 +1066,9 @@ extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
-    if (tile == 0) tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;   // ping-pong 256x256, else 128x128
+    if (tile == 0) {
+        tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
+    }
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
     if (tile == 6) tile = 7;
@@ -1116,7 +1111,7 @@ extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bi
     SLIME_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm: bad leading dims lda=%d ldc=%d", lda, ldc);
     SLIME_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) &&
                   (!bias || (uintptr_t)bias % 16 == 0), "gemm: pointers must be 16-byte aligned");
-    GemmArgs g{(const char*)A, (const char*)B, bias, C, lda, ldc, M, N, K, g_stagger, g_dbg};
+    GemmArgs g{(const char*)A, (const char*)B, bias, C, lda, ldc, M, N, K, g_group_m, g_dbg};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SLIME_BF16) return launch_T<BF16>(g, epilogue, s);
     if (dtype == SLIME_F16) return launch_T<F16>(g, epilogue, s);

@@ -227,6 +227,23 @@ def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
     assert rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype] * 1.5   # + P rounded to T before PV
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gain", [4.0, 12.0])
+def test_attention_large_logits(dev, dtype, gain):
+    """Logits with std 4 / 12: the reference max of the lazy-rescale softmax is refreshed many times,
+    and scores sit up to 8 log2-units above it in between (p up to 256 before normalisation)."""
+    from slime_amd import ops
+    B, S, heads, dh = 3, 577, 4, 64
+    E = heads * dh
+    q = _rand((B, S, E), dtype, dev, 40, gain * dh ** -0.5)
+    k = _rand((B, S, E), dtype, dev, 41)
+    v = _rand((B, S, E), dtype, dev, 42)
+    out = ops.attention(q, k, v, heads, dh)
+    ref = _attn_ref(q, k, v, heads, dh)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype] * 1.5
+
+
 def test_attention_packed_qkv_and_spike(dev):
     """q/k/v as thirds of one packed [B,S,3E] buffer (the tower's layout), and a forced running-max
     jump: one key row spiked against one query so the online-softmax rescale branch is exercised
