@@ -472,13 +472,13 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
                 mx = __builtin_fmaxf(mx, sc[s][1][3]);
-                mc[s] = rows_allmax(mx);
-                need |= mc[s] > m_run[s] + RESCALE_TH;
+                mc[s] = mx;                                  // this lane's 8 kv rows only: enough for the test
+                need |= mx > m_run[s] + RESCALE_TH;
             }
             if (__builtin_amdgcn_ballot_w64(need) != 0) {    // wave-uniform, rare
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s) {
-                    const float m_new = __builtin_fmaxf(m_run[s], mc[s]);
+                    const float m_new = __builtin_fmaxf(m_run[s], rows_allmax(mc[s]));   // row-uniform again
                     const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);   // exp2(-inf) = 0 on the first step
 #pragma unroll
                     for (int d = 0; d <= DT; ++d) o[s][d] *= alpha;
