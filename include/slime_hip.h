@@ -114,6 +114,27 @@ int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, i
 int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3_host,
                          const float* std3_host, void* out, int out_dtype, void* stream);
 
+/* ---- image slicer: Pillow-exact bicubic resize (replaces PIL Image.resize in resize_and_pad_image,
+ * mm_utils.py:99-131, and the global thumbnail, mm_utils.py:200) -------------------------------------
+ * Pillow's 8-bit resize is a two-pass separable convolution (horizontal, rounded to uint8, then vertical)
+ * whose per-output-pixel weights are normalised in double precision and converted to 22-bit fixed point.
+ * slime_resample_coeffs computes those tables on the HOST (pure C, no device work): bounds[2*o] = first
+ * source index, bounds[2*o+1] = tap count, kk[o*ksize + t] = fixed-point weight; ksize from
+ * slime_resample_ksize.  slime_resize_bicubic_u8 applies them on the device with integer arithmetic, so the
+ * result is bit-identical to Image.resize((out_w, out_h)) for RGB uint8 input. */
+int slime_resample_ksize(int in_size, int out_size);
+int slime_resample_coeffs(int in_size, int out_size, int* bounds_host, int* kk_host);
+
+/* src uint8 [src_h, src_w, 3] (row stride src_stride bytes) -> dst uint8 [out_h, out_w, 3] (row stride
+ * dst_stride bytes: dst may point inside a larger canvas = the centred paste of resize_and_pad_image).
+ * bounds_* / kk_* are DEVICE copies of the tables for (src_w -> out_w) and (src_h -> out_h); a pass whose
+ * sizes agree is skipped exactly as Pillow does (tables may be NULL for it).  tmp: src_h*out_w*3 bytes
+ * (only used when both passes run). */
+int slime_resize_bicubic_u8(const uint8_t* src, int src_h, int src_w, long src_stride, uint8_t* dst,
+                            long dst_stride, int out_h, int out_w, const int* bounds_h, const int* kk_h,
+                            int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v, uint8_t* tmp,
+                            size_t tmp_bytes, void* stream);
+
 /* Text-guided router, scores (TextGuidedRouterCosine.forward, resampler/builder.py:186-201):
  * scores[t] = sum_l mask[l] * cos(img[t], text[l]) (mean over l if mask is NULL); img fp32 [T,H], text fp32
  * [L,H], mask uint8 [L]; ws: L+H+4 floats of scratch. */

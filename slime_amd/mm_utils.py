@@ -3,7 +3,7 @@
 Same function names, arguments and behaviour as the reference (llava/mm_utils.py:14-259) so drivers
 can switch imports; written from the algorithm, not from the text.  This is host code (PIL): in
 the reference it runs inside forked DataLoader workers, where HIP is unavailable.  The on-device
-counterpart of the tile + normalise step is ``slime_tile_normalize`` (``process_anyres_image_gpu``).
+counterpart (``process_anyres_image_gpu``) runs resize + pad + tile + normalise in HIP, bit-identically.
 """
 from __future__ import annotations
 
@@ -114,19 +114,55 @@ def process_anyres_image(image: Image.Image, processor, grid_pinpoints) -> torch
     return torch.stack([processor.preprocess(v, return_tensors="pt")["pixel_values"][0] for v in views], dim=0)
 
 
-def process_anyres_image_gpu(image: Image.Image, processor, grid_pinpoints, device, dtype=torch.float32) -> torch.Tensor:
-    """Same result as :func:`process_anyres_image`, with tiling + rescale + normalise on the GPU
-    (``slime_tile_normalize``).  PIL still does the two resamplings (bit-exact PIL bicubic on device is
-    a later row); uint8 canvas + thumbnail go over PCIe (3 B/pixel instead of 12)."""
+def slice_image_gpu(image_u8: torch.Tensor, crop: int = CROP) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The slicer on the device: uint8 [H, W, 3] image (already in HBM) -> (uint8 [crop, crop, 3] global
+    thumbnail, uint8 padded local canvas), bit-identical to :func:`anyres_canvas` -- the uhd grid choice on
+    the host (integers), both bicubic resamplings in ``slime_resize_bicubic_u8`` (Pillow's fixed-point
+    arithmetic), the centred paste as the destination view of the second one."""
+    from . import ops
+    H, W, _ = image_u8.shape
+    tw, th = select_best_resolution_uhd((W, H), (crop, crop))
+    sw, sh = tw / W, th / H
+    if sw < sh:
+        nw, nh = tw, min(math.ceil(H * sw), th)
+    else:
+        nh, nw = th, min(math.ceil(W * sh), tw)
+    thumb = ops.resize_bicubic_u8(image_u8, crop, crop)
+    canvas = torch.zeros((th, tw, 3), dtype=torch.uint8, device=image_u8.device)
+    x0, y0 = (tw - nw) // 2, (th - nh) // 2
+    ops.resize_bicubic_u8(image_u8, nw, nh, out=canvas[y0:y0 + nh, x0:x0 + nw])
+    return thumb, canvas
+
+
+def process_anyres_image_gpu(image, processor, grid_pinpoints, device, dtype=torch.float32) -> torch.Tensor:
+    """Same result as :func:`process_anyres_image` (bit-identical in fp32) with the whole slicer on the GPU:
+    only the raw uint8 pixels cross PCIe; resize + pad (``slime_resize_bicubic_u8``), tiling, rescale and
+    normalise (``slime_tile_normalize``) run in HIP.  ``image``: PIL image or uint8 [H, W, 3] tensor.
+    Must be called from the main process (HIP is unusable in forked DataLoader workers)."""
     from . import ops
     _parse_pinpoints(grid_pinpoints)
-    thumb, canvas = anyres_canvas(image, processor)
+    if isinstance(image, Image.Image):
+        image = torch.from_numpy(np.array(image.convert("RGB")))
+    image = image.to(device, non_blocking=True)
     crop = processor.crop_size["height"]
-    t = torch.from_numpy(np.array(thumb.convert("RGB"))).to(device, non_blocking=True)
-    c = torch.from_numpy(np.array(canvas)).to(device, non_blocking=True)
-    g = ops.tile_normalize(t, crop, processor.image_mean, processor.image_std, dtype)
-    l = ops.tile_normalize(c, crop, processor.image_mean, processor.image_std, dtype)
+    thumb, canvas = slice_image_gpu(image, crop)
+    g = ops.tile_normalize(thumb, crop, processor.image_mean, processor.image_std, dtype)
+    l = ops.tile_normalize(canvas, crop, processor.image_mean, processor.image_std, dtype)
     return torch.cat([g, l], dim=0)
+
+
+def process_images_gpu(images, image_processor, model_cfg, device, dtype=torch.float32):
+    """Device counterpart of :func:`process_images` for the SliME mode (``image_aspect_ratio='anyres'``):
+    images (PIL or uint8 [H, W, 3] tensors, host or device) -> the same stacked tensor / list, resident on
+    ``device``.  Other modes raise: they are API-completeness modes of the reference served by the host path."""
+    mode = getattr(model_cfg, "image_aspect_ratio", None)
+    if mode != "anyres":
+        raise NotImplementedError(f"process_images_gpu implements image_aspect_ratio='anyres' only (got {mode!r}); "
+                                  "use process_images for the other modes")
+    out = [process_anyres_image_gpu(im, image_processor, model_cfg.image_grid_pinpoints, device, dtype) for im in images]
+    if all(x.shape == out[0].shape for x in out):
+        return torch.stack(out, dim=0)
+    return out
 
 
 def process_images(images: Sequence[Image.Image], image_processor, model_cfg) -> Union[torch.Tensor, List[torch.Tensor]]:

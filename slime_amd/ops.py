@@ -390,6 +390,59 @@ def tile_normalize(canvas_u8: torch.Tensor, crop: int, mean, std, out_dtype: tor
     return out
 
 
+def resample_tables(in_size: int, out_size: int):
+    """Host-side Pillow coefficient tables (int32 numpy arrays): bounds [out, 2], kk [out, ksize]."""
+    import numpy as np
+    lib = _lib.load()
+    ks = lib.slime_resample_ksize(in_size, out_size)
+    bounds = np.empty((out_size, 2), dtype=np.int32)
+    kk = np.empty((out_size, ks), dtype=np.int32)
+    _lib.check(lib.slime_resample_coeffs(in_size, out_size, bounds.ctypes.data, kk.ctypes.data), "slime_resample_coeffs")
+    return bounds, kk
+
+
+_TABLE_CACHE = {}
+
+
+def _device_tables(in_size: int, out_size: int, device: torch.device):
+    key = (in_size, out_size, str(device))
+    hit = _TABLE_CACHE.get(key)
+    if hit is None:
+        b, k = resample_tables(in_size, out_size)
+        hit = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), k.shape[1])
+        if len(_TABLE_CACHE) > 256:
+            _TABLE_CACHE.clear()
+        _TABLE_CACHE[key] = hit
+    return hit
+
+
+def resize_bicubic_u8(img_u8: torch.Tensor, out_w: int, out_h: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Bit-exact ``PIL.Image.resize((out_w, out_h))`` (default bicubic) of a uint8 [H, W, 3] device image.
+    ``out`` may be a [out_h, out_w, 3] view into a larger canvas (last two dims contiguous)."""
+    lib = _lib.load()
+    _require_cuda(img_u8, "image")
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or img_u8.shape[2] != 3:
+        raise ValueError(f"resize_bicubic_u8 expects a uint8 [H, W, 3] image, got {img_u8.dtype} {tuple(img_u8.shape)}")
+    if img_u8.stride(2) != 1 or img_u8.stride(1) != 3:
+        img_u8 = img_u8.contiguous()
+    H, W, _ = img_u8.shape
+    if out is None:
+        out = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=img_u8.device)
+    elif tuple(out.shape) != (out_h, out_w, 3) or out.stride(2) != 1 or out.stride(1) != 3 or out.dtype != torch.uint8:
+        raise ValueError("resize_bicubic_u8: out must be a uint8 [out_h, out_w, 3] view with packed pixels")
+    bh = kh = bv = kv = None
+    ksh = ksv = 0
+    if W != out_w:
+        bh, kh, ksh = _device_tables(W, out_w, img_u8.device)
+    if H != out_h:
+        bv, kv, ksv = _device_tables(H, out_h, img_u8.device)
+    tmp = torch.empty((H * out_w * 3,), dtype=torch.uint8, device=img_u8.device) if (bh is not None and bv is not None) else None
+    _lib.check(lib.slime_resize_bicubic_u8(img_u8.data_ptr(), H, W, img_u8.stride(0), out.data_ptr(), out.stride(0), out_h, out_w,
+                                           _ptr(bh), _ptr(kh), ksh, _ptr(bv), _ptr(kv), ksv, _ptr(tmp),
+                                           0 if tmp is None else tmp.numel(), _stream()), "slime_resize_bicubic_u8")
+    return out
+
+
 def router_scores(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
     """Cosine router scores [T] (fp32) for local tokens [T,H] against text embeddings [L,H]."""
     lib = _lib.load()

@@ -129,3 +129,16 @@ def test_adapter_state_dict_roundtrip():
     assert keys == set(asd.keys())
     assert enc.model.mm_projector.w_gate.dtype == torch.bfloat16 and enc.model.sampler.post_qformer.pos_embed.dtype == torch.float16
     assert enc.model.has_sampler and enc.model.sampler.grid_size == 12
+
+
+@pytest.mark.parametrize("sizes", [(672, 336), (1344, 336), (640, 672), (1080, 567), (300, 2352), (4000, 336),
+                                   (336, 337), (53, 336), (7, 3), (1, 336)])
+def test_resample_tables_match_oracle(sizes):
+    """Host half of the device slicer: the C ABI's Pillow coefficient tables (pure host function, no GPU)
+    equal the oracle's restatement bit for bit."""
+    from slime_amd import ops
+    from oracle import pil_resample as R
+    bounds, kk = ops.resample_tables(*sizes)
+    xmin, cnt, fixed = R.coefficients(*sizes)
+    assert np.array_equal(bounds[:, 0], xmin) and np.array_equal(bounds[:, 1], cnt)
+    assert np.array_equal(kk, fixed)

@@ -94,3 +94,39 @@ def test_grid_table():
     for (w, h), grid, uhd in zip(g["sizes"], g["grid"], g["uhd"]):
         assert O.select_best_resolution_uhd((int(w), int(h))) == tuple(uhd), (w, h)
         assert O.anyres_grid_shape((int(w), int(h))) == tuple(grid), (w, h)
+
+
+# ---- Pillow resample restatement (oracle/pil_resample.py): Pillow itself is the golden source -------------
+RESAMPLE_CASES = [((672, 672), (336, 336)), ((1344, 1344), (336, 336)), ((640, 480), (672, 504)),
+                  ((300, 200), (672, 448)), ((1500, 200), (1680, 224)), ((500, 336), (336, 336)),
+                  ((336, 500), (336, 226)), ((37, 53), (336, 336)), ((673, 672), (672, 672)), ((336, 336), (336, 336))]
+
+
+@pytest.mark.parametrize("src,dst", RESAMPLE_CASES)
+def test_pil_resample_restatement_matches_pillow(src, dst):
+    from PIL import Image
+    from oracle import pil_resample as R
+    (w, h), (ow, oh) = src, dst
+    img = np.random.default_rng(w * 7919 + h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh)))
+    assert np.array_equal(R.resize_bicubic_u8(img, ow, oh), ref)
+
+
+def test_pil_resample_slicer_matches_reference_pixels():
+    """uint8 slicer restatement (uhd grid -> resize+pad -> thumbnail) + CLIP normalisation reproduces the
+    reference's own ``process_images(..., 'anyres')`` pixels (slicer_pixels.npz) bit for bit."""
+    from oracle import pil_resample as R
+    from slime_amd.image_processor import ClipImageProcessor
+    g = np.load(os.path.join(GOLDEN, "slicer_pixels.npz"))
+    proc = ClipImageProcessor()
+    for i, (w, h) in enumerate(g["img_specs"]):
+        w, h = int(w), int(h)
+        arr = np.random.default_rng(100 + i).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        tw, th = O.select_best_resolution_uhd((w, h), (336, 336))
+        canvas = R.resize_and_pad_u8(arr, tw, th)
+        views = [R.resize_bicubic_u8(arr, 336, 336)]
+        views += [canvas[y:y + 336, x:x + 336] for y in range(0, th, 336) for x in range(0, tw, 336)]
+        out = np.stack([proc.normalize_u8(v) for v in views])
+        assert tuple(out.shape) == tuple(g[f"img{i}_anyres_shape"])
+        flat = out.reshape(out.shape[0], -1)
+        assert np.array_equal(flat[:, g["sample_idx"]].astype(np.float32), g[f"img{i}_anyres_samples"]), i
