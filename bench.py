@@ -161,22 +161,17 @@ def main():
     image_sizes = [(672, 672)] * IMAGES_PER_GPU
     g = model.sampler.grid_size
     rows_per_image = 576 + LOCAL_CROPS * g * g
-    from slime_amd.model.llava_arch import _split_indices
-    g_idx, l_idx = _split_indices(split_sizes, dev)
+    pg = model.mm_projector.packed(dt)
+    post = model.sampler.post_qformer.packed(576, dt)
 
     def step():
         feats = tower(pixels)                                                # [40,576,1024] bf16
         if world > 1:
             allf = sharded_tower_gather(feats, world)                        # [40*G,576,1024] on every rank
             feats = allf[rank * n_local:(rank + 1) * n_local]
-        glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)
-        comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)
-        loc = model.mm_projector(comp, out_dtype=torch.float32)
-        tokens = torch.empty((IMAGES_PER_GPU, rows_per_image, glob.shape[-1]), dtype=dt, device=dev)
-        for i in range(IMAGES_PER_GPU):
-            ti = tokens[i]
-            ops.merge_rows(glob[i:i + 1].contiguous(), ti, 0, 1, 1, 24, False)              # global rows, cast
-            ops.merge_rows(loc[i * LOCAL_CROPS:(i + 1) * LOCAL_CROPS].contiguous(), ti, 576, 2, 2, g, True)
+        # GatedBlock on the global crops + post_qformer / projection MLP / spatial merge on the local crops: one C-ABI
+        # call (slime_adapter_forward), tokens [images, 576 + 4*144, 4096] bf16
+        tokens = ops.adapter_forward(pg, post, feats, IMAGES_PER_GPU, LOCAL_CROPS, 2, 2, True, -1, dt)
         return tokens
 
     def barrier():

@@ -107,6 +107,22 @@ int slime_gather_rows(const float* in, int rows_in, int row_off, void* out, int 
 int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, int nw, int nh, int g,
                      int C, int merge, void* stream);
 
+/* Batched variants used by the fused adapter (same arithmetic): image b reads in + b*in_image_stride rows and
+ * writes out rows b*out_image_stride + dst_row0 + ...; gate_mix_ex writes row r to
+ * (r / rows_per_group) * group_stride + row0 + r % rows_per_group in out_dtype (F32/BF16/F16). */
+int slime_merge_rows_batched(const float* in, long in_image_stride, void* out, int out_dtype,
+                             long out_image_stride, long dst_row0, int images, int nw, int nh, int g, int C,
+                             int merge, void* stream);
+int slime_gate_mix_ex(const float* x, int D, const float* w_gate, const float* e0, const float* e1, void* out,
+                      int out_dtype, int rows, int H, int rows_per_group, long group_stride, long row0,
+                      void* stream);
+
+/* Select crops of every image from the tower output (the feat[0] / feat[1:] split of llava_arch.py:224-226):
+ * feats T [images*period, P, C]; output crop j = image (j / per_image) * period + first + j % per_image, written
+ * as fp32 rows (out_f32) and/or T rows (out_t), either may be NULL. */
+int slime_select_crops(const void* feats, int dtype, int P, int C, int period, int first, int per_image,
+                       int images, float* out_f32, void* out_t, void* stream);
+
 /* Tile + normalise on device: canvas uint8 [Hc, Wc, 3] (Hc, Wc multiples of `crop`) -> T/fp32
  * crops [ (Hc/crop)*(Wc/crop), 3, crop, crop ] in row-major tile order, value =
  * (u8 * (1/255) - mean[c]) / std[c]  (divide_to_patches mm_utils.py:134-153 + CLIPImageProcessor
@@ -233,6 +249,21 @@ size_t slime_gated_workspace_bytes(const slime_mlp_desc* mlp, const slime_resamp
 int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn,
                         const float* w_gate /* f32 [in_dim, 2] */, int learnable_gated,
                         const float* x, int n, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused adapter: everything between the tower and the router for a batch of images with the same
+ * crop layout (llava_arch.py:217-246: feat[0] -> mm_projector (GatedBlock), feat[1:] -> post_qformer ->
+ * mm_projector (MLP) -> spatial merge), as ONE launch sequence.  The three MLP passes (projection(x),
+ * projection(attn(x)), projection(post_qformer(local))) share weights and are row independent, so they run as
+ * one GEMM pair over the stacked rows; per-row results are identical to the separate calls.
+ *   feats: T [n_images*(1+n_local), 576, D] tower output, crop 0 of each image = global view.
+ *   out:   out_dtype [n_images, out_image_stride rows, H]; image i gets rows [0,576) = gated global tokens and
+ *          rows [576, 576 + n_local*g*g) = merged local tokens (raster order if merge != 0; nw*nh == n_local). */
+size_t slime_adapter_workspace_bytes(const slime_mlp_desc* mlp, const slime_resampler_desc* attn,
+                                     const slime_resampler_desc* post, int n_images, int n_local);
+int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, const float* w_gate,
+                          int learnable_gated, const slime_resampler_desc* post, const void* feats,
+                          int n_images, int n_local, int nw, int nh, int merge, void* out, int out_dtype,
+                          long out_image_stride, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

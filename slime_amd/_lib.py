@@ -68,6 +68,11 @@ _SIGNATURES = {
     "slime_resample_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "slime_resize_bicubic_u8": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_long, c_int, c_int, c_void_p, c_void_p,
                                         c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "slime_merge_rows_batched": (c_int, [c_void_p, c_long, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
+                                         c_int, c_void_p]),
+    "slime_gate_mix_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long,
+                                  c_long, c_void_p]),
+    "slime_select_crops": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "slime_tile_normalize": (c_int, [c_void_p, c_int, c_int, c_int, _P(c_float), _P(c_float), c_void_p, c_int, c_void_p]),
     "slime_router_scores": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "slime_router_select": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -84,11 +89,15 @@ _SIGNATURES = {
     "slime_gated_workspace_bytes": (c_size_t, [_P(MlpDesc), _P(ResamplerDesc), c_int]),
     "slime_gated_forward": (c_int, [_P(MlpDesc), _P(ResamplerDesc), c_void_p, c_int, c_void_p, c_int, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "slime_adapter_workspace_bytes": (c_size_t, [_P(MlpDesc), _P(ResamplerDesc), _P(ResamplerDesc), c_int, c_int]),
+    "slime_adapter_forward": (c_int, [_P(MlpDesc), _P(ResamplerDesc), c_void_p, c_int, _P(ResamplerDesc), c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_size_t, c_void_p]),
     # tuning hooks (not part of the reference-facing ABI)
     "slime_gemm_force_tile": (None, [c_int]),
     "slime_gemm_set_sched": (None, [c_int]),
     "slime_gemm_set_ablation": (None, [c_int]),
     "slime_gemm_set_group_m": (None, [c_int]),
+    "slime_gemm_set_shape_tile": (None, [c_int, c_int, c_int]),
     "slime_gemm_set_debug": (None, [c_void_p]),
     "slime_attention_set_debug": (None, [c_void_p]),
     "slime_attention_set_variant": (None, [c_int]),

@@ -300,3 +300,105 @@ extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resamp
         TRY(slime_gate_mix(x, mlp->in_dim, w_gate, e0, e1, out, rows, mlp->hidden, stream));
     return SLIME_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused adapter (GatedBlock on the global crops + post_qformer/MLP/merge on the local crops)
+// ------------------------------------------------------------------------------------------------
+struct AdapterPlan { size_t xg32, xl32, stack, e, mlp, res, total; long rows_g, rows_l, rows_all; int segs_g; };
+static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_desc* attn, const slime_resampler_desc* post,
+                                int n_images, int n_local, int learnable_gated) {
+    AdapterPlan p{};
+    const size_t D = m->in_dim, H = m->hidden;
+    p.rows_g = (long)n_images * attn->n_kv;
+    p.rows_l = post ? (long)n_images * n_local * post->n_query : 0;
+    p.segs_g = learnable_gated < 0 ? 2 : 1;
+    p.rows_all = p.segs_g * p.rows_g + p.rows_l;
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
+    p.xg32 = take((size_t)p.rows_g * D * 4);
+    p.xl32 = take(post ? (size_t)n_images * n_local * post->n_kv * D * 4 : 0);
+    p.stack = take((size_t)p.rows_all * D * 2);
+    p.e = take((size_t)p.rows_all * H * 4);
+    p.mlp = take(mlp_plan(m, (int)p.rows_all).total);
+    size_t res = res_plan(attn, n_images).total;
+    if (post && n_local > 0) { const size_t r2 = res_plan(post, n_images * n_local).total; if (r2 > res) res = r2; }
+    p.res = take(res);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+extern "C" size_t slime_adapter_workspace_bytes(const slime_mlp_desc* mlp, const slime_resampler_desc* attn,
+                                                const slime_resampler_desc* post, int n_images, int n_local) {
+    if (!mlp || !attn || n_images <= 0 || n_local < 0 || (n_local > 0 && !post)) return 0;
+    return adapter_plan(mlp, attn, n_local > 0 ? post : nullptr, n_images, n_local, -1).total;
+}
+
+extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, const float* w_gate,
+                                     int learnable_gated, const slime_resampler_desc* post, const void* feats,
+                                     int n_images, int n_local, int nw, int nh, int merge, void* out, int out_dtype,
+                                     long out_image_stride, void* ws, size_t ws_bytes, void* stream) {
+    TRY(mlp_validate(mlp));
+    TRY(resampler_validate(attn));
+    SLIME_REQUIRE(feats && out && n_images > 0 && n_local >= 0, "adapter: bad input");
+    SLIME_REQUIRE(attn->dim == mlp->in_dim && attn->n_query == attn->n_kv, "adapter: attn must map the token grid onto itself");
+    SLIME_REQUIRE(learnable_gated >= 0 || w_gate, "adapter: missing w_gate");
+    SLIME_REQUIRE(learnable_gated <= 1, "adapter: expert index %d", learnable_gated);
+    SLIME_REQUIRE(attn->dtype == mlp->dtype, "adapter: mixed operand dtypes");
+    int g = 0;
+    if (n_local > 0) {
+        TRY(resampler_validate(post));
+        SLIME_REQUIRE(post->dim == mlp->in_dim && post->n_kv == attn->n_kv && post->dtype == mlp->dtype, "adapter: post_qformer does not match the tower grid");
+        while (g * g < post->n_query) ++g;
+        SLIME_REQUIRE(g * g == post->n_query, "adapter: post_qformer query count %d is not a square grid", post->n_query);
+        SLIME_REQUIRE(nw > 0 && nh > 0 && nw * nh == n_local, "adapter: grid %dx%d does not hold %d local crops", nw, nh, n_local);
+    } else {
+        post = nullptr;
+    }
+    const int P = attn->n_kv, D = mlp->in_dim, H = mlp->hidden, dt = mlp->dtype;
+    const AdapterPlan p = adapter_plan(mlp, attn, post, n_images, n_local, learnable_gated);
+    SLIME_REQUIRE(out_image_stride >= P + (long)n_local * (post ? post->n_query : 0), "adapter: out_image_stride %ld too small", out_image_stride);
+    if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
+        slime_set_error("adapter: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, p.total);
+        return SLIME_EWORKSPACE;
+    }
+    char* w = (char*)ws;
+    float* xg32 = (float*)(w + p.xg32);
+    float* xl32 = (float*)(w + p.xl32);
+    char* stack = w + p.stack;
+    float* e = (float*)(w + p.e);
+    const size_t mlp_ws = mlp_plan(mlp, (int)p.rows_all).total;
+    const int period = 1 + n_local;
+
+    // stacked MLP input: [x_global | attn(x_global) | post_qformer(x_local)] (segments that are not needed are dropped)
+    size_t row = 0;
+    long seg_x = -1, seg_attn = -1, seg_local = -1;
+    if (learnable_gated != 1) { seg_x = (long)row; row += p.rows_g; }
+    if (learnable_gated != 0) { seg_attn = (long)row; row += p.rows_g; }
+    if (post) { seg_local = (long)row; row += p.rows_l; }
+
+    // global crops: fp32 copy for the resampler's LayerNorm and the gate logits, T copy straight into the stack
+    TRY(slime_select_crops(feats, dt, P, D, period, 0, 1, n_images, xg32, seg_x >= 0 ? stack + (size_t)seg_x * D * 2 : nullptr, stream));
+    if (seg_attn >= 0)
+        TRY(slime_resampler_forward(attn, xg32, D, n_images, nullptr, stack + (size_t)seg_attn * D * 2, w + p.res,
+                                    res_plan(attn, n_images).total, stream));
+    if (post) {
+        TRY(slime_select_crops(feats, dt, P, D, period, 1, n_local, n_images, xl32, nullptr, stream));
+        TRY(slime_resampler_forward(post, xl32, D, n_images * n_local, nullptr, stack + (size_t)seg_local * D * 2, w + p.res,
+                                    res_plan(post, n_images * n_local).total, stream));
+    }
+    TRY(slime_mlp_forward(mlp, nullptr, stack, (int)p.rows_all, e, w + p.mlp, mlp_ws, stream));
+
+    // global tokens -> rows [0, P) of every image
+    if (learnable_gated < 0) {
+        TRY(slime_gate_mix_ex(xg32, D, w_gate, e + (size_t)seg_x * H, e + (size_t)seg_attn * H, out, out_dtype, (int)p.rows_g, H,
+                              P, out_image_stride, 0, stream));
+    } else {
+        const long seg = learnable_gated == 0 ? seg_x : seg_attn;
+        // flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)
+        TRY(slime_merge_rows_batched(e + (size_t)seg * H, P, out, out_dtype, out_image_stride, 0, n_images, P, 1, 1, H, 0, stream));
+    }
+    if (post)
+        TRY(slime_merge_rows_batched(e + (size_t)seg_local * H, (long)n_local * post->n_query, out, out_dtype, out_image_stride, P,
+                                     n_images, nw, nh, g, H, merge, stream));
+    return SLIME_OK;
+}

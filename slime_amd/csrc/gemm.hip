@@ -1062,12 +1062,22 @@ static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
+// bench hook: per-shape tile override table (N, K) -> tile, consulted in auto mode; tile 0 clears the table
+static int g_rule_n[8], g_rule_k[8], g_rule_tile[8], g_rules = 0;
+extern "C" void slime_gemm_set_shape_tile(int N, int K, int tile) {
+    if (tile == 0) { g_rules = 0; return; }
+    for (int i = 0; i < g_rules; ++i)
+        if (g_rule_n[i] == N && g_rule_k[i] == K) { g_rule_tile[i] = tile; return; }
+    if (g_rules < 8) { g_rule_n[g_rules] = N; g_rule_k[g_rules] = K; g_rule_tile[g_rules] = tile; ++g_rules; }
+}
 
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
     if (tile == 0) {
         tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
+        for (int i = 0; i < g_rules; ++i)
+            if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     }
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;

@@ -222,8 +222,20 @@ extern "C" int slime_embed_prenorm(const float* patch_out, const float* cls, con
 // ------------------------------------------------------------------------------------------------
 // Gate mix: (g0,g1) = softmax(x @ w_gate) / (sum + 1e-6);  out = g0*e0 + g1*e1.  One wave per row.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store4_cast(void* base, size_t elem, int out_dtype, float4 v) {
+    if (out_dtype == SLIME_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + elem) = v;
+    } else {
+        u32x2 p = {T::pack2(v.x, v.y), T::pack2(v.z, v.w)};
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(base) + elem * 2) = p;
+    }
+}
+
+// out row of input row r: (r / rows_per_group) * group_stride + row0 + r % rows_per_group  (token buffer of an image batch)
 __global__ void __launch_bounds__(256) gate_mix_kernel(const float* x, int D, const float* wg, const float* e0,
-                                                       const float* e1, float* out, int rows, int H) {
+                                                       const float* e1, void* out, int out_dtype, int rows, int H,
+                                                       int rows_per_group, long group_stride, long row0) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -243,21 +255,30 @@ __global__ void __launch_bounds__(256) gate_mix_kernel(const float* x, int D, co
     const float g0 = s0 / den, g1 = s1 / den;
     const float* a = e0 + (size_t)row * H;
     const float* b = e1 + (size_t)row * H;
-    float* o = out + (size_t)row * H;
+    const size_t orow = (size_t)(row / rows_per_group) * group_stride + row0 + row % rows_per_group;
     for (int c = lane * 4; c < H; c += 256) {
         const float4 u = *reinterpret_cast<const float4*>(a + c);
         const float4 w = *reinterpret_cast<const float4*>(b + c);
-        *reinterpret_cast<float4*>(o + c) = make_float4(g0 * u.x + g1 * w.x, g0 * u.y + g1 * w.y,
-                                                        g0 * u.z + g1 * w.z, g0 * u.w + g1 * w.w);
+        const float4 v = make_float4(g0 * u.x + g1 * w.x, g0 * u.y + g1 * w.y, g0 * u.z + g1 * w.z, g0 * u.w + g1 * w.w);
+        if (out_dtype == SLIME_F16) store4_cast<F16>(out, orow * H + c, out_dtype, v);
+        else store4_cast<BF16>(out, orow * H + c, out_dtype, v);
     }
+}
+
+extern "C" int slime_gate_mix_ex(const float* x, int D, const float* w_gate, const float* e0, const float* e1, void* out,
+                                 int out_dtype, int rows, int H, int rows_per_group, long group_stride, long row0,
+                                 void* stream) {
+    SLIME_REQUIRE(x && w_gate && e0 && e1 && out && rows > 0 && H % 4 == 0 && rows_per_group > 0, "gate_mix: bad input");
+    SLIME_REQUIRE(out_dtype == SLIME_F32 || out_dtype == SLIME_BF16 || out_dtype == SLIME_F16, "gate_mix: bad out dtype");
+    hipLaunchKernelGGL(gate_mix_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate, e0, e1, out,
+                       out_dtype, rows, H, rows_per_group, group_stride, row0);
+    SLIME_CHECK_LAUNCH("gate_mix");
+    return SLIME_OK;
 }
 
 extern "C" int slime_gate_mix(const float* x, int D, const float* w_gate, const float* e0, const float* e1,
                               float* out, int rows, int H, void* stream) {
-    SLIME_REQUIRE(x && w_gate && e0 && e1 && out && rows > 0 && H % 4 == 0, "gate_mix: bad input");
-    hipLaunchKernelGGL(gate_mix_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate, e0, e1, out, rows, H);
-    SLIME_CHECK_LAUNCH("gate_mix");
-    return SLIME_OK;
+    return slime_gate_mix_ex(x, D, w_gate, e0, e1, out, SLIME_F32, rows, H, rows > 0 ? rows : 1, 0, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -300,10 +321,11 @@ extern "C" int slime_gather_rows(const float* in, int rows_in, int row_off, void
     return SLIME_OK;
 }
 
-__global__ void __launch_bounds__(256) merge_rows_kernel(const float* in, void* out, int out_dtype, long dst_row0,
-                                                         int nw, int nh, int g, int C, int merge) {
+__global__ void __launch_bounds__(256) merge_rows_kernel(const float* in, long in_image_stride, void* out, int out_dtype,
+                                                         long out_image_stride, long dst_row0, int nw, int nh, int g,
+                                                         int C, int merge) {
     const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // input row: (crop k, qy, qx)
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // input row of this image: (crop k, qy, qx)
     const long total = (long)nw * nh * g * g;
     if (r >= total) return;
     long dst = r;
@@ -312,18 +334,63 @@ __global__ void __launch_bounds__(256) merge_rows_kernel(const float* in, void* 
         const int gx = k % nw, gy = k / nw;
         dst = ((long)(gy * g + qy) * nw + gx) * g + qx;
     }
-    const float* src = in + (size_t)r * C;
-    if (out_dtype == SLIME_F16) store_row_cast<F16>(src, out, (size_t)(dst_row0 + dst), C, out_dtype, lane);
-    else store_row_cast<BF16>(src, out, (size_t)(dst_row0 + dst), C, out_dtype, lane);
+    const float* src = in + ((size_t)blockIdx.y * in_image_stride + (size_t)r) * C;
+    const size_t drow = (size_t)blockIdx.y * out_image_stride + dst_row0 + dst;
+    if (out_dtype == SLIME_F16) store_row_cast<F16>(src, out, drow, C, out_dtype, lane);
+    else store_row_cast<BF16>(src, out, drow, C, out_dtype, lane);
+}
+
+extern "C" int slime_merge_rows_batched(const float* in, long in_image_stride, void* out, int out_dtype,
+                                        long out_image_stride, long dst_row0, int images, int nw, int nh, int g, int C,
+                                        int merge, void* stream) {
+    SLIME_REQUIRE(in && out && images > 0 && nw > 0 && nh > 0 && g > 0 && C % 4 == 0, "merge_rows: bad input");
+    const long total = (long)nw * nh * g * g;
+    hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((total + 3) / 4), images), dim3(256), 0, (hipStream_t)stream,
+                       in, in_image_stride, out, out_dtype, out_image_stride, dst_row0, nw, nh, g, C, merge);
+    SLIME_CHECK_LAUNCH("merge_rows");
+    return SLIME_OK;
 }
 
 extern "C" int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, int nw, int nh, int g,
                                 int C, int merge, void* stream) {
-    SLIME_REQUIRE(in && out && nw > 0 && nh > 0 && g > 0 && C % 4 == 0, "merge_rows: bad input");
-    const long total = (long)nw * nh * g * g;
-    hipLaunchKernelGGL(merge_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       in, out, out_dtype, dst_row0, nw, nh, g, C, merge);
-    SLIME_CHECK_LAUNCH("merge_rows");
+    return slime_merge_rows_batched(in, 0, out, out_dtype, 0, dst_row0, 1, nw, nh, g, C, merge, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Crop gather for the adapter: T features [crops, P, C] -> fp32 (and optionally T) rows of the selected
+// crops: output crop j = image (j / per_image) * period + first + j % per_image.  One wave per row,
+// 16 B per lane per step.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) select_crops_kernel(const char* feats, int P, int C, int period, int first,
+                                                           int per_image, long rows, float* out_f32, char* out_t) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long j = r / P, i = r % P;
+    const long crop = (j / per_image) * period + first + j % per_image;
+    const char* src = feats + ((size_t)crop * P + i) * C * 2;
+    for (int c = lane * 8; c < C; c += 512) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)c * 2);
+        if (out_t) *reinterpret_cast<u32x4*>(out_t + ((size_t)r * C + c) * 2) = v;
+        if (out_f32) {
+            float* d = out_f32 + (size_t)r * C + c;
+            *reinterpret_cast<float4*>(d) = make_float4(T::lo(v[0]), T::hi(v[0]), T::lo(v[1]), T::hi(v[1]));
+            *reinterpret_cast<float4*>(d + 4) = make_float4(T::lo(v[2]), T::hi(v[2]), T::lo(v[3]), T::hi(v[3]));
+        }
+    }
+}
+
+extern "C" int slime_select_crops(const void* feats, int dtype, int P, int C, int period, int first, int per_image,
+                                  int images, float* out_f32, void* out_t, void* stream) {
+    SLIME_REQUIRE(feats && (out_f32 || out_t) && P > 0 && C % 8 == 0 && per_image > 0 && images > 0, "select_crops: bad input");
+    SLIME_REQUIRE(first >= 0 && first + per_image <= period, "select_crops: window outside the image's crops");
+    SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "select_crops: features must be BF16 or F16");
+    const long rows = (long)images * per_image * P;
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == SLIME_F16) hipLaunchKernelGGL(select_crops_kernel<F16>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)feats, P, C, period, first, per_image, rows, out_f32, (char*)out_t);
+    else hipLaunchKernelGGL(select_crops_kernel<BF16>, grid, dim3(256), 0, (hipStream_t)stream, (const char*)feats, P, C, period, first, per_image, rows, out_f32, (char*)out_t);
+    SLIME_CHECK_LAUNCH("select_crops");
     return SLIME_OK;
 }
 

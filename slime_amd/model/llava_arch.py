@@ -11,7 +11,11 @@ but scheduled for the GPU instead of per image: the reference loops over images 
 ViT once per image (llava_arch.py:222); here ALL crops of the batch go through the tower as one batch,
 all global views through one GatedBlock launch sequence and all local crops through one
 post_qformer + MLP sequence; only the tiny data-dependent tail (merge, router, concat) is per image.
-The tower hands fp32 features to the adapter (the reference hands over fp16/bf16).
+When every image of the batch has the same crop layout (the usual case: one resolution bucket per batch) the
+whole adapter -- both experts of the GatedBlock, post_qformer, the shared projection MLP over the stacked rows,
+gate mix and spatial merge -- is ONE C-ABI call (``slime_adapter_forward``) on the tower's 16-bit features, as
+in the reference, which hands fp16/bf16 features to its adapter; ragged batches take the per-module sequence,
+where the tower hands over fp32 features.
 
 ``SlimeMetaForCausalLM`` can be mixed into an HF causal LM exactly like ``LlavaMetaForCausalLM``
 (INTEGRATION.md); ``SlimeVisualEncoder`` is the standalone form used by bench.py and the tests.
@@ -25,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from .multimodal_encoder.builder import build_vision_tower
-from .multimodal_projector.builder import build_vision_projector, GatedBlock
+from .multimodal_projector.builder import build_vision_projector, GatedBlock, _operand_dtype
 from .multimodal_resampler.builder import build_vision_sampler
 from .. import ops
 from ..constants import IMAGE_TOKEN_INDEX
@@ -41,6 +45,36 @@ def _split_indices(split_sizes, device):
         l.extend(range(off + 1, off + s))
         off += s
     return (torch.tensor(g, dtype=torch.long, device=device), torch.tensor(l, dtype=torch.long, device=device))
+
+
+def _uniform_layout(split_sizes, image_sizes, cfg, crop: int, merge_type: str):
+    """(n_local, nw, nh, merge) when all images share one crop count and one grid, else None."""
+    if not split_sizes or any(s != split_sizes[0] for s in split_sizes):
+        return None
+    n_local = split_sizes[0] - 1
+    if n_local == 0:
+        return (0, 1, 1, False)
+    if merge_type == "flat":
+        return (n_local, n_local, 1, False)
+    if merge_type != "spatial" or image_sizes is None:
+        return None
+    grids = {tuple(get_anyres_image_grid_shape(sz, cfg.image_grid_pinpoints, crop)) for sz in image_sizes}
+    if len(grids) != 1:
+        return None
+    nw, nh = next(iter(grids))
+    return (n_local, nw, nh, True) if nw * nh == n_local else None
+
+
+def _fused_adapter(model, images: torch.Tensor, layout, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None):
+    """tower -> slime_adapter_forward for a uniform batch: tokens [B, 576 + n*g*g, H]."""
+    n_local, nw, nh, merge = layout
+    tower = model.get_vision_tower()
+    T = _operand_dtype(images, model.mm_projector.projection[0].weight)
+    feats = tower(images, out_dtype=T)
+    B = feats.shape[0] // (1 + n_local)
+    post = model.sampler.post_qformer.packed(feats.shape[1], T) if n_local else None
+    return ops.adapter_forward(model.mm_projector.packed(T), post, feats, B, n_local, nw, nh, merge,
+                               int(model.mm_projector.learnable_gated), out_dtype, out)
 
 
 class SlimeMetaModel:
@@ -109,8 +143,21 @@ class SlimeMetaForCausalLM(ABC):
         if model.has_sampler and split_sizes is not None:
             sep = model.embed_tokens(torch.tensor(cfg.seperator, dtype=input_ids.dtype, device=input_ids.device))
             text_emb, text_mask = self.get_pure_text_embedding(input_ids, attention_mask, labels)
-            feats = tower(images, out_dtype=torch.float32)                      # [sum(1+n_i), 576, D], one batch
             B = len(split_sizes)
+            layout = None
+            if (getattr(cfg, "fused_adapter", True) and isinstance(model.mm_projector, GatedBlock) and images_mask is None
+                    and not use_local_only and not use_global_only):
+                layout = _uniform_layout(list(split_sizes), image_sizes, cfg, tower.config.image_size, merge_type)
+            if layout is not None and layout[0] > 0:
+                tokens = _fused_adapter(model, images, layout, torch.float32)        # [B, 576 + n*g*g, H] fp32
+                P = tower.num_patches
+                sep32 = sep.to(device=tokens.device, dtype=torch.float32).unsqueeze(0)
+                outs = []
+                for i in range(B):
+                    routed = model.sampler(tokens[i, P:], text_embedding=text_emb[i], attn_mask=text_mask[i])
+                    outs.append(torch.cat([tokens[i, :P], sep32, routed], dim=0).to(out_dtype).unsqueeze(0))
+                return outs, split_sizes
+            feats = tower(images, out_dtype=torch.float32)                      # [sum(1+n_i), 576, D], one batch
             dev = feats.device
             g_idx, l_idx = _split_indices(split_sizes, dev)
             glob = loc = None
@@ -226,6 +273,12 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         model = self.model
         tower = model.get_vision_tower()
         merge = merge or getattr(self.config, "mm_patch_merge_type", "flat")
+        if getattr(self.config, "fused_adapter", True) and isinstance(model.mm_projector, GatedBlock):
+            layout = _uniform_layout(list(split_sizes), image_sizes, self.config, tower.config.image_size, merge)
+            if layout is not None and layout[0] > 0:
+                tokens = _fused_adapter(model, images, layout, torch.float32)
+                P = tower.num_patches
+                return [(tokens[i, :P], tokens[i, P:]) for i in range(len(split_sizes))]
         feats = tower(images, out_dtype=torch.float32)
         dev = feats.device
         g_idx, l_idx = _split_indices(split_sizes, dev)

@@ -362,6 +362,33 @@ def gated_forward(pg: PackedGated, x: torch.Tensor, learnable_gated: int = -1) -
     return out
 
 
+def adapter_forward(pg: PackedGated, post: Optional["PackedResampler"], feats: torch.Tensor, n_images: int, n_local: int,
+                    nw: int, nh: int, merge: bool = True, learnable_gated: int = -1,
+                    out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused adapter for images that share one crop layout: tower features T [n_images*(1+n_local), 576, D] ->
+    tokens [n_images, 576 + n_local*g*g, H] (gated global rows, then the merged local rows).  ``out`` may be a
+    wider [n_images, rows, H] buffer (extra rows per image are left untouched)."""
+    lib = _lib.load()
+    _require_cuda(feats, "feats")
+    if feats.dtype != pg.mlp.dtype:
+        feats = feats.to(pg.mlp.dtype)
+    feats = feats.contiguous()
+    assert feats.shape[0] == n_images * (1 + n_local) and feats.shape[1] == pg.attn.n_kv and feats.shape[2] == pg.mlp.in_dim
+    rows = pg.attn.n_kv + (n_local * post.n_query if n_local else 0)
+    if out is None:
+        out = torch.empty((n_images, rows, pg.mlp.hidden), dtype=out_dtype or feats.dtype, device=feats.device)
+    assert out.dim() == 3 and out.shape[0] == n_images and out.shape[1] >= rows and out.shape[2] == pg.mlp.hidden and out.is_contiguous()
+    pdesc = C.byref(post.desc) if n_local else None
+    need = lib.slime_adapter_workspace_bytes(C.byref(pg.mlp.desc), C.byref(pg.attn.desc), pdesc, n_images, n_local)
+    ws = pg.ws.get(need, feats.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_adapter_forward(C.byref(pg.mlp.desc), C.byref(pg.attn.desc), pg.w_gate.data_ptr(), int(learnable_gated),
+                                         pdesc, feats.data_ptr(), n_images, n_local, nw, nh, int(merge), out.data_ptr(),
+                                         dtype_code(out.dtype), out.shape[1], base, ws.numel() - (base - ws.data_ptr()),
+                                         _stream()), "slime_adapter_forward")
+    return out
+
+
 def merge_rows(local: torch.Tensor, out: torch.Tensor, dst_row0: int, nw: int, nh: int, grid: int, merge: bool):
     """Scatter [n, g*g, C] fp32 local tokens into ``out`` rows (spatial raster order or flat), casting."""
     lib = _lib.load()

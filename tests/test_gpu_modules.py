@@ -264,3 +264,69 @@ def test_tower_list_edge_cases(dev):
     assert len(one) == 1 and one[0].shape == (1, 576, 128)
     with pytest.raises(ValueError, match="doesn't match model"):
         tower(torch.zeros(1, 3, 224, 224, device=dev))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("gated", [-1, 0, 1])
+def test_fused_adapter_equals_module_sequence(dev, dtype, gated):
+    """slime_adapter_forward (stacked MLP, batched gate mix + merge, one C call) against the per-module launch
+    sequence on the same 16-bit tower features: same kernels on the same rows -> equal to rounding noise
+    (bit-equal unless the GEMM tile choice differs with M), plus the untouched padding rows of a wider buffer."""
+    from slime_amd import ops, weights as W
+    enc, _, _ = _tiny_encoder(dev, dtype, mm_learnable_gated=gated)
+    model = enc.get_model()
+    model.mm_projector.learnable_gated = gated
+    B, n_local, nw, nh = 3, 6, 2, 3
+    feats = torch.randn(B * (1 + n_local), 576, 128, device=dev).to(dtype)
+    f32 = feats.float()
+    g_idx = torch.arange(0, B * (1 + n_local), 1 + n_local, device=dev)
+    l_idx = torch.tensor([i for i in range(B * (1 + n_local)) if i % (1 + n_local)], device=dev)
+    pg = model.mm_projector.packed(dtype)                      # explicit operand dtype for both sides
+    post = model.sampler.post_qformer.packed(576, dtype)
+    glob = ops.gated_forward(pg, f32.index_select(0, g_idx), gated)
+    comp = ops.resampler_forward(post, f32.index_select(0, l_idx))
+    loc = ops.mlp_forward(pg.mlp, comp.reshape(-1, 128)).reshape(B * n_local, -1, 256)
+    g = model.sampler.grid_size
+    ref = torch.empty((B, 576 + n_local * g * g, 256), dtype=torch.float32, device=dev)
+    for i in range(B):
+        ref[i, :576] = glob[i]
+        ops.merge_rows(loc[i * n_local:(i + 1) * n_local].contiguous(), ref[i], 576, nw, nh, g, True)
+    out = ops.adapter_forward(pg, post, feats, B, n_local, nw, nh, True, gated, torch.float32)
+    assert out.shape == ref.shape
+    assert rel_l2(out.cpu(), ref.cpu()) < 1e-6, float((out - ref).abs().max())
+    # 16-bit output into a wider token buffer: rows beyond the image's tokens stay untouched
+    wide = torch.full((B, ref.shape[1] + 5, 256), 3.0, dtype=dtype, device=dev)
+    ops.adapter_forward(pg, post, feats, B, n_local, nw, nh, True, gated, out=wide)
+    assert torch.equal(wide[:, :ref.shape[1]], ref.to(dtype)) or rel_l2(wide[:, :ref.shape[1]].float().cpu(), ref.cpu()) < 2e-3
+    assert bool((wide[:, ref.shape[1]:] == 3.0).all())
+    # flat order and a global-only batch
+    flat = ops.adapter_forward(pg, post, feats, B, n_local, n_local, 1, False, gated, torch.float32)
+    assert rel_l2(flat[:, 576:].cpu(), loc.reshape(B, n_local * g * g, 256).cpu()) < 1e-6
+    only_g = ops.adapter_forward(pg, None, feats[:4], 4, 0, 1, 1, False, gated, torch.float32)
+    ref_g = ops.gated_forward(pg, f32[:4].contiguous(), gated)
+    assert only_g.shape == (4, 576, 256) and rel_l2(only_g.cpu(), ref_g.cpu()) < 1e-6
+
+
+def test_fused_adapter_full_dims_and_errors(dev):
+    """SliME-8B adapter dims (1024 -> 4096, 8 x 128 heads), 2 images x (1+4): fused == module sequence; bad grids raise."""
+    from slime_amd import ops, weights as W
+    from slime_amd._lib import SlimeHipError
+    dtype = torch.bfloat16
+    asd = W.make_adapter_state_dict(W.ADAPTER_8B, seed=5)
+    pg = ops.pack_gated(W.sub_state(asd, "mm_projector."), W.ADAPTER_8B, dtype, dev)
+    post = ops.pack_resampler(W.sub_state(asd, "sampler.post_qformer."), 1024, 8, 576, dtype, dev, W.ADAPTER_8B.ln_eps)
+    B, n = 2, 4
+    feats = torch.randn(B * (1 + n), 576, 1024, device=dev).to(dtype)
+    f32 = feats.float()
+    out = ops.adapter_forward(pg, post, feats, B, n, 2, 2, True, -1, torch.float32)
+    glob = ops.gated_forward(pg, f32[0::5].contiguous())
+    loc_idx = [i for i in range(B * 5) if i % 5]
+    comp = ops.resampler_forward(post, f32[loc_idx].contiguous())
+    loc = ops.mlp_forward(pg.mlp, comp.reshape(-1, 1024)).reshape(B * n, 144, 4096)
+    assert rel_l2(out[:, :576].cpu(), glob.cpu()) < 1e-6
+    ref_l = torch.empty((B, n * 144, 4096), dtype=torch.float32, device=dev)
+    for i in range(B):
+        ops.merge_rows(loc[i * n:(i + 1) * n].contiguous(), ref_l[i], 0, 2, 2, 12, True)
+    assert rel_l2(out[:, 576:].cpu(), ref_l.cpu()) < 1e-6
+    with pytest.raises(SlimeHipError, match="grid"):
+        ops.adapter_forward(pg, post, feats, B, n, 3, 2, True, -1, torch.float32)
