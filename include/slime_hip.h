@@ -82,11 +82,13 @@ int slime_embed_prenorm(const float* patch_out, const float* cls, const float* p
                         const float* ln_b, float eps, float* h, int n, int P, int D, void* stream);
 
 /* Fused multi-head attention, softmax(Q K^T) V with fp32 online softmax; Q is expected PRE-SCALED
- * by head_dim^-0.5 (folded into the q projection weights; exact, the scale is a power of two).
+ * by head_dim^-0.5 * log2(e) (SLIME_ATTN_Q_PRESCALE, folded into the q projection weights and bias at pack
+ * time): the logits then arrive in log2 units and the kernels evaluate 2^x with v_exp_f32 directly.
  *   q: T, element (b, i, h, d) at q[b*q_bs + i*q_rs + h*head_dim + d]   (q_bs may be 0: shared queries)
  *   k, v likewise with (k_bs,k_rs), (v_bs,v_rs);  o: T at o[b*o_bs + i*o_rs + h*head_dim + d].
  * head_dim 64 (CLIP self-attention, HF :259-277) or 128 (Resampler nn.MultiheadAttention,
  * sampler.py:128,162-165). */
+#define SLIME_LOG2E 1.4426950408889634
 int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
                     const void* v, long v_bs, long v_rs, void* o, long o_bs, long o_rs,
                     int batch, int heads, int head_dim, int n_q, int n_kv, int dtype, void* stream);
@@ -178,8 +180,8 @@ typedef struct {
     const float* pre_ln_w; const float* pre_ln_b;
     /* per-layer tensors, contiguous over layers (layer stride = the per-layer element count) */
     const float* ln1_w; const float* ln1_b; /* f32 [L, hidden]                                            */
-    const void*  w_qkv;                     /* T   [L, 3*hidden, hidden], q rows pre-scaled by dh^-0.5    */
-    const float* b_qkv;                     /* f32 [L, 3*hidden]          (q part pre-scaled)             */
+    const void*  w_qkv;                     /* T   [L, 3*hidden, hidden], q rows x dh^-0.5*log2(e)       */
+    const float* b_qkv;                     /* f32 [L, 3*hidden]          (q part scaled likewise)        */
     const void*  w_o;   const float* b_o;   /* T   [L, hidden, hidden]; f32 [L, hidden]                   */
     const float* ln2_w; const float* ln2_b;
     const void*  w_fc1; const float* b_fc1; /* T   [L, inter, hidden];  f32 [L, inter]                    */
@@ -211,7 +213,7 @@ int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels, int pix_dt
 typedef struct {
     int dim, heads, n_query, n_kv, dtype;
     float eps;
-    const void*  q_proj;                    /* T   [n_query, dim]: ((ln_q(query)+pos_embed) Wq^T + bq) * dh^-0.5, input independent */
+    const void*  q_proj;                    /* T   [n_query, dim]: ((ln_q(query)+pos_embed) Wq^T + bq) * dh^-0.5 * log2(e), input independent */
     const float* pos_k;                     /* f32 [n_kv, dim]: get_abs_pos(pos_embed, kv grid)           */
     const float* ln_kv_w; const float* ln_kv_b;
     const void*  w_k; const float* b_k;     /* T [dim, dim]; f32 [dim]                                    */

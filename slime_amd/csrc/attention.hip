@@ -18,7 +18,7 @@
 //
 // LDS images: K rows are 16-B-chunk XOR-swizzled for conflict-free ds_read_b128; V rows are swizzled
 // at 8-B granularity so that the 8 rows x 4 pieces a half-wave transpose-read touches cover all 64
-// banks.  Softmax statistics are fp32; exp via v_exp_f32 (exp2) on log2e-scaled scores.
+// banks.  Softmax statistics are fp32; scores arrive in log2 units (q carries dh^-0.5 * log2 e), exp via v_exp_f32.
 #include "common.h"
 
 struct AttnArgs {
@@ -71,7 +71,6 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
     constexpr int KS = DH / 32;           // k-steps of the QK^T contraction
     constexpr int DT = DH / 16;           // 16-row tiles of O^T
     constexpr int NT = NW * 64;
-    constexpr float LOG2E = 1.4426950408889634f;
     char* Klds = smem;
     char* Vlds = smem + KC * RB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -200,18 +199,18 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
                     mx = rows_allmax(mx);
                     const float m_new = fmaxf(m_run[s], mx);
                     if (__builtin_amdgcn_ballot_w64(m_new != m_run[s]) != 0) {     // wave-uniform: some row's max moved
-                        const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[s] - m_new);
                         l_run[s] *= alpha;
 #pragma unroll
                         for (int d = 0; d < DT; ++d) o[s][d] *= alpha;
                         m_run[s] = m_new;
                     }
-                    const float mneg = -m_run[s] * LOG2E;
+                    const float mneg = -m_run[s];
                     float p[8];
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[s][t][r], LOG2E, mneg));
+                        for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(sc[s][t][r] + mneg);
                     l_run[s] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                     const u32x4 pf = pack8<T>(p);
 #pragma unroll
@@ -316,14 +315,20 @@ static int launch_attn(const AttnArgs& a0, int batch, hipStream_t stream) {
 // visible ds_read that may alias a DMA destination with s_waitcnt vmcnt(0), which would drain the second
 // K/V half before the first MFMA.  The DMA/barrier ordering is explicit in attn64_body; consumers are
 // ordered behind these reads by lgkm_wait_*(), which name the destination registers as "+v".
+// OFF: compile-time byte offset folded into the instruction's 16-bit offset field (inline asm hides the address
+// arithmetic from the compiler, which would otherwise spend one v_add_u32 per read on it).
+template <int OFF>
 __device__ __forceinline__ u32x4 lds_b128_asm(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     u32x4 r;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
+template <int OFF>
 __device__ __forceinline__ u32x2 lds_tr16_asm(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
 __device__ __forceinline__ unsigned lds_addr(const char* p) {
@@ -334,8 +339,7 @@ template <typename T, int NSUB>
 __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
     constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608, NW = 8;
     constexpr int ROWS1 = 320;                             // first DMA half (10 steps)
-    constexpr float LOG2E = 1.4426950408889634f;
-    constexpr float RESCALE_TH = 8.0f / LOG2E;
+    constexpr float RESCALE_TH = 8.0f;                     // log2 units: p = exp2(s - m_ref) <= 256 between refreshes
     char* Klds = smem;
     char* Vlds = smem + KC * RB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -400,56 +404,60 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
         // o[s][0..3]: O^T d-tiles; o[s][4]: the row-sum tile (A operand = a constant fragment whose row 0 is
         // all ones, so the matrix pipe accumulates sum_kv P[q][kv] in row 0 -- the VALU is the bound here;
         // measured: lane-local fp32 sums instead are 3 % slower).
-        f32x4 o[NSUB][DT + 1];
+        // Scores are in log2 units (q carries dh^-0.5 * log2 e) and leave the matrix pipe ALREADY relative to the
+        // reference max: the QK accumulator starts from cinit = -m_run instead of 0, so p = exp2(score) needs no
+        // per-score subtract/scale on the VALU (which cannot overlap with the MFMA stream on this chip: a plain VALU
+        // instruction beyond ~1 per MFMA costs ~6 cycles of matrix time, tools/mfma_valu_mix.hip).
+        f32x4 o[NSUB][DT + 1], cinit[NSUB];
         float m_run[NSUB];
 #pragma unroll
         for (int s = 0; s < NSUB; ++s) {
-            m_run[s] = -INFINITY;
+            m_run[s] = 0.f;                                  // provisional; the first step always refreshes it
+            cinit[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int d = 0; d <= DT; ++d) o[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const unsigned one2 = T::pack2(1.0f, 1.0f);
         const unsigned onew = (li == 0) ? one2 : 0u;
         const u32x4 ones = {onew, onew, onew, onew};
-        int koff[KS];
+        // Running per-lane LDS pointers (advanced by one 32-row kv step per call, 4 v_add per step); everything else
+        // is an immediate: K fragment (t, ks) at kptr[ks] + t*16*RB, V^T fragment (t, dt) at vptr[dt >> 1] + t*16*RB
+        // + (dt & 1)*8.
+        unsigned kptr[KS], vptr[2];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) koff[ks] = li * RB + (((ks * 4 + g) ^ (lane & 7)) << 4);
-        int voff[DT];
+        for (int ks = 0; ks < KS; ++ks) kptr[ks] = lds_addr(Klds) + li * RB + (((ks * 4 + g) ^ (lane & 7)) << 4);
         {
             const int vrow = 4 * g + (li >> 2);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                voff[dt] = vrow * RB + (((4 * (dt >> 1) + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4) + (dt & 1) * 8;
+            for (int hh = 0; hh < 2; ++hh)
+                vptr[hh] = lds_addr(Vlds) + vrow * RB + (((4 * hh + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4);
         }
-        const unsigned kbase_lds = lds_addr(Klds), vbase_lds = lds_addr(Vlds);
-
         auto qk = [&](int st, f32x4 (&sc)[NSUB][2]) {
-            const unsigned kp = kbase_lds + st * 32 * RB;
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) { sc[s][0] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[s][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             u32x4 kf[2][KS];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = lds_b128_asm(kp + t * 16 * RB + koff[ks]);
+                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = t == 0 ? lds_b128_asm<0>(kptr[ks]) : lds_b128_asm<16 * RB>(kptr[ks]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;      // qk is called for st = 0, 1, 2, ... in order
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], sc[s][t]);
+                    for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], ks == 0 ? cinit[s] : sc[s][t]);
         };
         // One kv step for all sub-blocks, branch free (one basic block: the scheduler may interleave the
         // independent sub-block chains and the MFMAs with the VALU stream).
-        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], bool masked) {
-            const unsigned vp = vbase_lds + st * 32 * RB;
+        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], f32x4 (&nxt)[NSUB][2], bool has_next, bool masked) {
             u32x2 v0[DT], v1[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                v0[dt] = lds_tr16_asm(vp + voff[dt]);
-                v1[dt] = lds_tr16_asm(vp + 16 * RB + voff[dt]);
+                v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1]) : lds_tr16_asm<0>(vptr[dt >> 1]);
+                v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1]) : lds_tr16_asm<16 * RB>(vptr[dt >> 1]);
             }
+            vptr[0] += 32 * RB; vptr[1] += 32 * RB;         // softmax_pv is called for st = 0, 1, 2, ... in order
             if (masked) {                                    // ragged tail: kv >= n_kv -> -inf (selects, no branch)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -460,10 +468,10 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                         for (int s = 0; s < NSUB; ++s) sc[s][t][r] = dead ? -INFINITY : sc[s][t][r];
                     }
             }
-            // Lazy rescale: m_run is a REFERENCE max, refreshed only when some query of the wave sees a score
-            // more than 8 (log2 units) above it, so p = exp2(s - m_run) <= 256 -- harmless in fp32 sums and in
-            // 16-bit P (same relative precision) -- and the 20 multiplies + exp of the accumulator rescale
-            // leave the steady-state VALU stream (it fires in the first step or two of a sub-block).
+            // Lazy rescale: m_run is a REFERENCE max, refreshed only when some query of the wave sees a score more
+            // than 8 log2 units above it (p <= 256 in between: harmless in fp32 sums and in 16-bit P) and on the
+            // first step.  Refreshing rescales the accumulators, moves cinit, and re-bases the scores that are
+            // already in registers (this step's and, double buffered, the next step's).
             float mc[NSUB];
             bool need = false;
 #pragma unroll
@@ -473,21 +481,28 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
                 mx = __builtin_fmaxf(mx, sc[s][1][3]);
                 mc[s] = mx;                                  // this lane's 8 kv rows only: enough for the test
-                need |= mx > m_run[s] + RESCALE_TH;
+                need |= mx > RESCALE_TH;
             }
-            if (__builtin_amdgcn_ballot_w64(need) != 0) {    // wave-uniform, rare
+            if (__builtin_amdgcn_ballot_w64(need) != 0 || st == 0) {    // wave-uniform, rare
 #pragma unroll
                 for (int s = 0; s < NSUB; ++s) {
-                    const float m_new = __builtin_fmaxf(m_run[s], rows_allmax(mc[s]));   // row-uniform again
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[s] - m_new) * LOG2E);   // exp2(-inf) = 0 on the first step
+                    float d = rows_allmax(mc[s]);            // excess of this step's row max over the reference
+                    d = st == 0 ? d : __builtin_fmaxf(d, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-                    for (int d = 0; d <= DT; ++d) o[s][d] *= alpha;
-                    m_run[s] = m_new;
+                    for (int dd = 0; dd <= DT; ++dd) o[s][dd] *= alpha;
+                    m_run[s] += d;
+                    const float c = -m_run[s];
+                    cinit[s] = f32x4{c, c, c, c};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sc[s][t][r] -= d;
+                            if (has_next) nxt[s][t][r] -= d;
+                        }
                 }
             }
-            float mneg[NSUB];
-#pragma unroll
-            for (int s = 0; s < NSUB; ++s) mneg[s] = -m_run[s] * LOG2E;
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
                                                    "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
             u32x4 vf[DT];
@@ -499,7 +514,7 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sc[s][t][r], LOG2E, mneg[s]));
+                    for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(sc[s][t][r]);
                 const u32x4 pf = pack8<T>(p);
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
@@ -522,18 +537,18 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
         for (; st + 2 < steps; st += 2) {                    // neither st nor st+1 is the last step
             second_half_ready(st + 1);
             qk(st + 1, sB);                                  // next step's scores under this step's softmax
-            softmax_pv(st, sA, false);
+            softmax_pv(st, sA, sB, true, false);
             second_half_ready(st + 2);
             qk(st + 2, sA);
-            softmax_pv(st + 1, sB, false);
+            softmax_pv(st + 1, sB, sA, true, false);
         }
         if (st + 2 == steps) {
             second_half_ready(st + 1);
             qk(st + 1, sB);
-            softmax_pv(st, sA, false);
-            softmax_pv(st + 1, sB, ragged);
+            softmax_pv(st, sA, sB, true, false);
+            softmax_pv(st + 1, sB, sA, false, ragged);
         } else {
-            softmax_pv(st, sA, ragged);
+            softmax_pv(st, sA, sB, false, ragged);
         }
 
         char* obase = a.o + ((size_t)b * a.o_bs + (size_t)h * DH) * 2;

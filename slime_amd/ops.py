@@ -17,6 +17,8 @@ import torch.nn.functional as F
 from . import _lib
 from .weights import VisionConfig, AdapterConfig, strip_tower_prefix, sub_state
 
+LOG2E = 1.4426950408889634   # slime_attention takes q pre-scaled by head_dim^-0.5 * log2(e)
+
 _DT = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.F32, torch.uint8: _lib.U8}
 
 
@@ -87,7 +89,7 @@ def layernorm(x: torch.Tensor, w, b, eps: float, dtype: torch.dtype, want_f32=Fa
 
 
 def attention(q, k, v, heads: int, head_dim: int) -> torch.Tensor:
-    """q [B|1, nq, H*dh] (pre-scaled), k/v [B, nkv, H*dh] -> [B, nq, H*dh]; all T, last dim contiguous."""
+    """q [B|1, nq, H*dh] (pre-scaled by dh^-0.5 * log2 e), k/v [B, nkv, H*dh] -> [B, nq, H*dh]; all T, last dim contiguous."""
     lib = _lib.load()
     B, nkv = k.shape[0], k.shape[1]
     nq = q.shape[1]
@@ -138,7 +140,7 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
     D, Fi, L = cfg.hidden_size, cfg.intermediate_size, layers_for_select(cfg, select_layer)
     P2 = 3 * cfg.patch_size * cfg.patch_size
     kpad = (P2 + 63) // 64 * 64
-    scale = cfg.head_dim ** -0.5
+    scale = cfg.head_dim ** -0.5 * LOG2E                     # logits in log2 units (slime_attention contract)
 
     def f32(t):
         return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -247,7 +249,7 @@ def pack_resampler(sd: Dict[str, torch.Tensor], dim: int, heads: int, n_kv: int,
     in_w, in_b = sd["attn.in_proj_weight"].float().cpu(), sd["attn.in_proj_bias"].float().cpu()
     pos_q = sd["pos_embed"].cpu()
     q = F.layer_norm(sd["query"].float().cpu(), (E,), sd["ln_q.weight"].float().cpu(), sd["ln_q.bias"].float().cpu(), eps)
-    q = F.linear(q + pos_q.float(), in_w[:E], in_b[:E]) * dh ** -0.5
+    q = F.linear(q + pos_q.float(), in_w[:E], in_b[:E]) * (dh ** -0.5 * LOG2E)
     pos_k = _abs_pos(pos_q, side).float()
 
     def f32(t):

@@ -197,12 +197,15 @@ def test_tile_normalize(dev):
 
 
 # -------------------------------------------------------------------------------------- attention
+LOG2E = 1.4426950408889634
+
+
 def _attn_ref(q, k, v, heads, dh):
     B, nq = k.shape[0], q.shape[1]
     qf = q.float().expand(B, -1, -1).reshape(B, nq, heads, dh).transpose(1, 2)
     kf = k.float().reshape(B, -1, heads, dh).transpose(1, 2)
     vf = v.float().reshape(B, -1, heads, dh).transpose(1, 2)
-    att = torch.softmax(qf @ kf.transpose(-1, -2), -1)      # q already carries the scale
+    att = torch.softmax(qf @ kf.transpose(-1, -2) / LOG2E, -1)   # q carries dh^-0.5 * log2(e): logits in log2 units
     return (att @ vf).transpose(1, 2).reshape(B, nq, heads * dh)
 
 
@@ -219,7 +222,7 @@ def _attn_ref(q, k, v, heads, dh):
 def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
     from slime_amd import ops
     E = heads * dh
-    q = _rand((1 if shared_q else B, nq, E), dtype, dev, 30, dh ** -0.5)
+    q = _rand((1 if shared_q else B, nq, E), dtype, dev, 30, dh ** -0.5 * LOG2E)
     k = _rand((B, nkv, E), dtype, dev, 31)
     v = _rand((B, nkv, E), dtype, dev, 32)
     out = ops.attention(q, k, v, heads, dh)
@@ -235,7 +238,7 @@ def test_attention_large_logits(dev, dtype, gain):
     from slime_amd import ops
     B, S, heads, dh = 3, 577, 4, 64
     E = heads * dh
-    q = _rand((B, S, E), dtype, dev, 40, gain * dh ** -0.5)
+    q = _rand((B, S, E), dtype, dev, 40, gain * dh ** -0.5 * LOG2E)
     k = _rand((B, S, E), dtype, dev, 41)
     v = _rand((B, S, E), dtype, dev, 42)
     out = ops.attention(q, k, v, heads, dh)
@@ -252,7 +255,7 @@ def test_attention_packed_qkv_and_spike(dev):
     B, S, heads, dh = 2, 577, 2, 64
     E = heads * dh
     qkv = _rand((B, S, 3 * E), torch.bfloat16, dev, 33)
-    qkv[..., :E] *= dh ** -0.5
+    qkv[..., :E] *= dh ** -0.5 * LOG2E
     qkv[0, 500, E:2 * E] = qkv[0, 17, :E] * 60.0            # k[500] aligned with q[17]: huge logit at kv=500
     q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
     out = ops.attention(q, k, v, heads, dh)

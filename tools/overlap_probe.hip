@@ -25,6 +25,21 @@ __global__ void k(float* out, unsigned long long* cyc, int mode_lo, int mode_hi,
 #pragma unroll
             for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]);
         }
+    } else if (mode == 5) {          // plain VALU only: 32 fma per rep (8 independent chains x 4)
+        for (int r = 0; r < REP; ++r) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[i] = fmaf(x[i], 1.0001f, 0.5f);
+        }
+    } else if (mode == 6) {          // one stream: 4 MFMAs, then 8 exps (block structure like the attention step)
+        for (int r = 0; r < REP; ++r) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     } else if (mode == 3) {          // interleaved in ONE stream: 4 MFMAs + 4*valu_per_mfma plain VALU (fma) per rep
         for (int r = 0; r < REP; ++r) {
 #pragma unroll
@@ -56,6 +71,9 @@ int main() {
         {"MFMA only, 1 wave/SIMD (4 MFMA/rep)", 256, 1, 0, 0}, {"exp only, 1 wave/SIMD (8 exp/rep)", 256, 2, 0, 0},
         {"MFMA || MFMA, 2 waves/SIMD", 512, 1, 1, 0}, {"exp || exp, 2 waves/SIMD", 512, 2, 2, 0},
         {"MFMA(w0-3) || exp(w4-7), 2 waves/SIMD", 512, 1, 2, 0},
+        {"fma only, 1 wave/SIMD (32 fma/rep)", 256, 5, 0, 0}, {"fma || fma, 2 waves/SIMD", 512, 5, 5, 0},
+        {"MFMA(w0-3) || fma(w4-7)", 512, 1, 5, 0}, {"fma(w0-3) || MFMA(w4-7)", 512, 5, 1, 0}, {"exp(w0-3) || MFMA(w4-7)", 512, 2, 1, 0},
+        {"1 wave: 4 MFMA then 8 exp", 256, 6, 0, 0}, {"2 waves: 4 MFMA then 8 exp each", 512, 6, 6, 0},
         {"1 wave: 4x(MFMA + 4 fma)", 256, 3, 0, 4}, {"1 wave: 4x(MFMA + 8 fma)", 256, 3, 0, 8},
         {"2 waves: 4x(MFMA + 8 fma) each", 512, 3, 3, 8}, {"1 wave: 4x(MFMA + 2 exp)", 256, 4, 0, 0}, {"2 waves: 4x(MFMA + 2 exp) each", 512, 4, 4, 0}};
     for (auto& c : cases) {
