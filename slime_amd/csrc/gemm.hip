@@ -41,6 +41,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * one_plus_erf;
 }
 
+// Pin a wave-uniform pointer into SGPRs (the compiler otherwise folds `uniform + lane offset + uniform` into 64-bit
+// VALU adds and loses the SGPR-base addressing mode of global_load_lds).
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// One LDS-DMA piece in the SGPR-base form (64 lanes x 16 B -> 1 KiB at LDS byte address lds_addr, lane-linear):
+// hipcc materialises a 64-bit VGPR address per piece from the builtin (v_lshl_add_u64 + the vaddr form) inside loops,
+// so the instruction is written out.  M0 = LDS base; one wait state between the M0 write and the load.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const char* p) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
+}
+
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
@@ -376,7 +395,12 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 
     // ---- LDS-DMA pieces owned by this wave: kind 0 = A quarter (rows 0..63 of the group's half),
     // kind 1 = B half 0 part, kind 2 = B half 1 part, kind 3 = A quarter (rows 64..127); 2 pieces each.
-    const char* src[4][2];
+    // Sources are (wave-uniform 64-bit base) + (per-lane 32-bit byte offset) so that the DMA is the SGPR-base form of
+    // global_load_lds: half the address VGPR traffic per piece and no 64-bit VALU pointer arithmetic in the L sections;
+    // the k advance is a scalar add on the base.
+    const char* a_base = g.A + (size_t)m0 * g.lda * 2;
+    const char* b_base = g.B + (size_t)n0 * g.K * 2;
+    unsigned soff[4][2];
     int dst[4][2];                                       // byte offset inside a stage
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -384,8 +408,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int qa = 0; qa < 2; ++qa) {                 // A quarters
             const int row = grp * 128 + qa * 64 + piece * 8;
-            const int gm = min(m0 + row + lrow, g.M - 1);
-            src[qa ? 3 : 0][j] = g.A + ((size_t)gm * g.lda) * 2 + lchunk * 16;
+            const int rl = min(row + lrow, g.M - 1 - m0);           // clamp: rows past M re-read the last row
+            soff[qa ? 3 : 0][j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
             dst[qa ? 3 : 0][j] = row * 128;
         }
 #pragma unroll
@@ -394,17 +418,16 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             const int rho = chunk * 64 + hb * 32 + sub * 8 + lrow;
             const int nl = rho & 15;
             const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-            src[1 + hb][j] = g.B + ((size_t)(n0 + nphys) * g.K) * 2 + lchunk * 16;
+            soff[1 + hb][j] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
             dst[1 + hb][j] = A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
         }
     }
     auto issue = [&](int kind, int tile) {               // 2 pieces of `kind` for k-tile `tile`
         char* base = smem + (tile & 1) * STAGE;
+        const char* gb = uniform_ptr((kind == 0 || kind == 3 ? a_base : b_base) + (size_t)tile * (BK * 2));
+        const unsigned lb = __builtin_amdgcn_readfirstlane(lds_byte_addr(base));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(src[kind][j]), LDS_PTR(base + dst[kind][j]), 16, 0, 0);
-            src[kind][j] += BK * 2;
-        }
+        for (int j = 0; j < 2; ++j) lds_dma16(soff[kind][j], gb, lb + dst[kind][j]);
     };
 
     int a_off[2], b_off[2];
