@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run gather + adapter of a step on the tower's stream instead of a second stream")
     return ap.parse_args()
 
 
@@ -137,8 +139,13 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SLIME_BENCH_FORCE_COLLECTIVE=1: take the N>1 code path (RCCL init, all-gather, barrier, max-reduce) with a
+    # single rank -- a self-test of that path on a 1-GPU box; the timed step then includes the 1-rank all-gather.
+    collective = world > 1 or os.environ.get("SLIME_BENCH_FORCE_COLLECTIVE") == "1"
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from slime_amd import weights as W, ops
@@ -164,18 +171,32 @@ def main():
     pg = model.mm_projector.packed(dt)
     post = model.sampler.post_qformer.packed(576, dt)
 
-    def step():
-        feats = tower(pixels)                                                # [40,576,1024] bf16
-        if world > 1:
+    # Steps are independent batches, so the tail of step i (all-gather + adapter: small, partly under-filled launches,
+    # and for N > 1 an xGMI transfer) is enqueued on its own stream and runs under the tower of step i+1; the timed
+    # region ends with a device-wide synchronize, i.e. all K steps are complete inside it.
+    tail_stream = None if args.no_pipeline else torch.cuda.Stream(device=dev)
+
+    def tail(feats):
+        if collective:
             allf = sharded_tower_gather(feats, world)                        # [40*G,576,1024] on every rank
             feats = allf[rank * n_local:(rank + 1) * n_local]
         # GatedBlock on the global crops + post_qformer / projection MLP / spatial merge on the local crops: one C-ABI
         # call (slime_adapter_forward), tokens [images, 576 + 4*144, 4096] bf16
-        tokens = ops.adapter_forward(pg, post, feats, IMAGES_PER_GPU, LOCAL_CROPS, 2, 2, True, -1, dt)
-        return tokens
+        return ops.adapter_forward(pg, post, feats, IMAGES_PER_GPU, LOCAL_CROPS, 2, 2, True, -1, dt)
+
+    def step():
+        feats = tower(pixels)                                                # [40,576,1024] bf16
+        if tail_stream is None:
+            return tail(feats)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(tail_stream):
+            tail_stream.wait_event(ready)
+            feats.record_stream(tail_stream)
+            return tail(feats)
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -190,7 +211,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert torch.isfinite(out.float()).all()
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -219,7 +240,8 @@ def main():
                                    "tower + gated adapter + post_qformer + MLP projector + spatial merge",
                        "crops_per_gpu": n_local, "images_per_gpu": IMAGES_PER_GPU, "grid": "1+4",
                        "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),
-                       "tower_streams": halves},
+                       "tower_streams": halves,
+                       "step_pipelining": "none" if tail_stream is None else "gather+adapter of step i on a second stream, under the tower of step i+1"},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
                           "gflop_per_step_per_gpu": round(step_gf, 1)},
             "roofline": {"bound": "mfma",
@@ -234,7 +256,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
