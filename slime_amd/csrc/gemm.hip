@@ -362,9 +362,12 @@ gemm_kernel(GemmArgs g) {
 // profilers report the short-K and long-K launches of one epilogue as separate kernels.
 // ABL (timing ablations only, results are wrong for ABL != 0): bit0 = no LDS-DMA in the main loop,
 // bit1 = no fragment ds_reads in the main loop, bit2 = no barriers in the main loop.
-template <typename T, int EPI, int KTAG, int ABL = 0>
+template <typename T, int EPI, int KTAG, int ABL = 0, int MT = 4>
 __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
-    constexpr int BM = 256, BN = 256, BK = 64;
+    // MT = 16-row MFMA tiles per quadrant: 4 -> 256-row workgroup tile, 3 -> 192 rows (a group's A half is 32*MT rows,
+    // a phase is 4*MT MFMAs).  The 192-row tile exists for grid quantisation: 11540 rows x N=1024 are 184 tiles of 256
+    // rows (0.72 rounds of 256 CUs) but 244 tiles of 192 rows (0.95 rounds of 3/4-size workgroups).
+    constexpr int BM = 64 * MT, BN = 256, BK = 64, HALF = 32 * MT, QROWS = 16 * MT;
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -407,7 +410,9 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
         const int piece = wn * 2 + j;                    // 0..7 inside the group's share
 #pragma unroll
         for (int qa = 0; qa < 2; ++qa) {                 // A quarters
-            const int row = grp * 128 + qa * 64 + piece * 8;
+            // a quarter has 2*MT pieces of 8 rows; at MT = 3 wave 3's two slots repeat piece 5 (same bytes, keeps the
+            // per-wave DMA count -- and with it the counted vmcnt -- uniform)
+            const int row = grp * HALF + qa * QROWS + min(piece, 2 * MT - 1) * 8;
             const int rl = min(row + lrow, g.M - 1 - m0);           // clamp: rows past M re-read the last row
             soff[qa ? 3 : 0][j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
             dst[qa ? 3 : 0][j] = row * 128;
@@ -434,13 +439,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int sw = ((ks * 4 + lq) ^ (lane & 7)) << 4;
-        a_off[ks] = (grp * 128 + li) * 128 + sw;
+        a_off[ks] = (grp * HALF + li) * 128 + sw;
         b_off[ks] = A_BYTES + (wn * 64 + li) * 128 + sw;
     }
 
-    f32x4 acc[8][4];
+    f32x4 acc[2 * MT][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 2 * MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -457,7 +462,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if constexpr ((ABL & 8) != 0) t_pro = __builtin_amdgcn_s_memtime();
     if (grp == 1) PP_BARRIER();                          // group 1 runs one slot behind
 
-    u32x4 af[4][2], bf[2][2][2];
+    u32x4 af[MT][2], bf[2][2][2];
     for (int t = 0; t < nk; ++t) {
         const char* sb = smem + (t & 1) * STAGE;
 #pragma unroll
@@ -473,10 +478,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             }
             if ((p == 0 || p == 2) && (!(ABL & 2) || t == 0)) {
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
-                        af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (mh * 64 + mi * 16) * 128);
+                        af[mi][ks] = *reinterpret_cast<const u32x4*>(sb + a_off[ks] + (mh * QROWS + mi * 16) * 128);
             }
             if ((p == 1) && (!(ABL & 2) || t == 0)) {
 #pragma unroll
@@ -501,10 +506,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                     for (int nj = 0; nj < 2; ++nj)
-                        acc[mh * 4 + mi][nh * 2 + nj] = T::mfma16(bf[nh][nj][ks], af[mi][ks], acc[mh * 4 + mi][nh * 2 + nj]);
+                        acc[mh * MT + mi][nh * 2 + nj] = T::mfma16(bf[nh][nj][ks], af[mi][ks], acc[mh * MT + mi][nh * 2 + nj]);
             __builtin_amdgcn_s_setprio(0);
             if (!(ABL & 4)) PP_BARRIER();
         }
@@ -512,8 +517,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
     if constexpr ((ABL & 8) != 0) t_loop = __builtin_amdgcn_s_memtime();
 
-    if (m0 + BM <= g.M) epilogue_wave<T, EPI, 8, 4, true>(g, acc, m0 + grp * 128 + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
-    else epilogue_wave<T, EPI, 8, 4, false>(g, acc, m0 + grp * 128 + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
+    if (m0 + BM <= g.M) epilogue_wave<T, EPI, 2 * MT, 4, true>(g, acc, m0 + grp * HALF + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
+    else epilogue_wave<T, EPI, 2 * MT, 4, false>(g, acc, m0 + grp * HALF + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
     if constexpr ((ABL & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0 && g.dbg) {
@@ -1027,17 +1032,18 @@ extern "C" void slime_gemm_set_debug(void* p) { g_dbg = (unsigned long long*)p; 
 extern "C" void slime_gemm_set_ablation(int a) { g_ablation = a; }
 extern "C" void slime_gemm_set_group_m(int s) { g_group_m = s; }
 
-template <typename T, int EPI, int KTAG, int ABL>
+template <typename T, int EPI, int KTAG, int ABL, int MT = 4>
 static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
-    constexpr int LDS = 2 * (256 + 256) * 64 * 2;
-    auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL>;
+    constexpr int BM = 64 * MT;
+    constexpr int LDS = 2 * (BM + 256) * 64 * 2;
+    auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL, MT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) { slime_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
         attr_set = true;
     }
-    const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_pp");
     return SLIME_OK;
@@ -1057,6 +1063,11 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
         }
     }
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0>(g, stream) : launch_pp_k<T, EPI, 0, 0>(g, stream);
+}
+
+template <typename T, int EPI>
+static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
+    return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0, 3>(g, stream) : launch_pp_k<T, EPI, 0, 0, 3>(g, stream);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
@@ -1081,7 +1092,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
 // covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
 // running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong (default), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
+static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong (auto picks 4 or 9), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
@@ -1099,17 +1110,30 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     int tile = g_force_tile;
     if (tile == 0) {
         tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
+        if (tile == 4) {
+            // Row-tile height by grid quantisation, for grids of at least one full round of 256 CUs: rounds x per-
+            // workgroup time (~ rows + a fixed share).  qkv at 11540 rows: 552 tiles of 256 rows = 3 rounds, 732 tiles
+            // of 192 rows = 3 rounds of 3/4-size workgroups (772 -> 866 TF/s).  Sub-round grids (out_proj / fc2: 184
+            // tiles) would gain even more stand-alone (994 -> 1216 TF/s) but LOSE 2.5 % inside the two-stream tower,
+            // where the idle CUs of a 0.72-round launch are taken by the other stream's kernels: they keep 256 rows.
+            const long tn = g.N / 256;
+            const long n256 = ((g.M + 255) / 256) * tn, n192 = ((g.M + 191) / 192) * tn;
+            const long c256 = (n256 + 255) / 256 * (256 + 40);
+            const long c192 = (n192 + 255) / 256 * (192 + 40);
+            if (n256 >= 256 && c192 < c256) tile = 9;
+        }
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     }
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
-    if (tile == 6) tile = 7;
+    if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
     if (tile == 5) return launch_ppp<T, EPI>(g, stream);
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
+    if (tile == 9) return launch_pp192<T, EPI>(g, stream);
     if (g_sched == 0) {
         switch (tile) {
             case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream);

@@ -17,10 +17,10 @@ def run():
         with torch.cuda.stream(s): ops.tower_forward(pt, p)
     for s in streams: cur.wait_stream(s)
 SHAPES = {"qkv": (3072, 1024), "out": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
-CONFIGS = [(), ("out",), ("qkv",), ("fc2",), ("fc1",), ("out", "qkv"), ("out", "fc2"), ("out", "qkv", "fc2")]
+CONFIGS = [(), ("qkv", "out", "fc2", "fc1"), ("out", "fc2"), ("qkv",)]
 for _ in range(3): run()
 for rep in range(2):
-    for tile in (3, 1):
+    for tile in (4,):          # auto = cost-model rule (192-row tile for qkv/out/fc2); listed shapes forced back to 256 rows
         for cfg in CONFIGS:
             lib.slime_gemm_set_shape_tile(0, 0, 0)
             for name in cfg: lib.slime_gemm_set_shape_tile(*SHAPES[name], tile)
@@ -29,4 +29,6 @@ for rep in range(2):
             for _ in range(8): run()
             torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 8
             print(f"tile {tile} for {'+'.join(cfg) or 'none':12s}: {t*1e3:.2f} ms {40/t:.0f} crops/s", flush=True)
+lib.slime_gemm_set_shape_tile(0, 0, 0)
+
 lib.slime_gemm_set_shape_tile(0, 0, 0)
