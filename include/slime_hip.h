@@ -153,6 +153,18 @@ int slime_resize_bicubic_u8(const uint8_t* src, int src_h, int src_w, long src_s
                             int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v, uint8_t* tmp,
                             size_t tmp_bytes, void* stream);
 
+/* Batched forms for `images` equally sized images (one launch per pass for the whole batch): image b reads
+ * src + b*src_image_stride and writes dst + b*dst_image_stride (bytes); tmp: images*src_h*out_w*3 bytes.
+ * slime_tile_normalize_batched writes the tiles of canvas b to crops [b*out_image_crops + tile] of `out`, so the
+ * global thumbnail (one tile) and the local tiles of an image can be laid out as its (1 + n) consecutive crops. */
+int slime_resize_bicubic_u8_batched(const uint8_t* src, int images, long src_image_stride, int src_h, int src_w,
+                                    long src_stride, uint8_t* dst, long dst_image_stride, long dst_stride, int out_h,
+                                    int out_w, const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v,
+                                    const int* kk_v, int ksize_v, uint8_t* tmp, size_t tmp_bytes, void* stream);
+int slime_tile_normalize_batched(const uint8_t* canvas, int images, long canvas_image_stride, int Hc, int Wc,
+                                 int crop, const float* mean3_host, const float* std3_host, void* out,
+                                 long out_image_crops, int out_dtype, void* stream);
+
 /* Text-guided router, scores (TextGuidedRouterCosine.forward, resampler/builder.py:186-201):
  * scores[t] = sum_l mask[l] * cos(img[t], text[l]) (mean over l if mask is NULL); img fp32 [T,H], text fp32
  * [L,H], mask uint8 [L]; ws: L+H+4 floats of scratch. */

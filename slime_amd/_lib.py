@@ -73,6 +73,10 @@ _SIGNATURES = {
     "slime_gate_mix_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long,
                                   c_long, c_void_p]),
     "slime_select_crops": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "slime_resize_bicubic_u8_batched": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_long, c_void_p, c_long, c_long, c_int, c_int,
+                                                c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "slime_tile_normalize_batched": (c_int, [c_void_p, c_int, c_long, c_int, c_int, c_int, _P(c_float), _P(c_float), c_void_p, c_long,
+                                             c_int, c_void_p]),
     "slime_tile_normalize": (c_int, [c_void_p, c_int, c_int, c_int, _P(c_float), _P(c_float), c_void_p, c_int, c_void_p]),
     "slime_router_scores": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "slime_router_select": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -400,15 +400,17 @@ extern "C" int slime_select_crops(const void* feats, int dtype, int P, int C, in
 // LDS, and each channel row is written coalesced.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* canvas, int Hc, int Wc, int crop,
-                                                             float3 mean, float3 sd, void* out, int out_dtype) {
+__global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* canvas, long canvas_image_stride, int Hc, int Wc,
+                                                             int crop, float3 mean, float3 sd, void* out, long out_image_crops,
+                                                             int out_dtype) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint8_t* line = reinterpret_cast<uint8_t*>(smem);
     const int tiles_x = Wc / crop;
     const int y = blockIdx.x % crop;
     const int tile = blockIdx.x / crop;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint8_t* src = canvas + ((size_t)(ty * crop + y) * Wc + (size_t)tx * crop) * 3;
+    // image b (blockIdx.y): canvas b -> crops [b * out_image_crops + tile]
+    const uint8_t* src = canvas + (size_t)blockIdx.y * canvas_image_stride + ((size_t)(ty * crop + y) * Wc + (size_t)tx * crop) * 3;
     for (int i = threadIdx.x; i < crop * 3; i += blockDim.x) line[i] = src[i];
     __syncthreads();
     const float m[3] = {mean.x, mean.y, mean.z}, sdv[3] = {sd.x, sd.y, sd.z};
@@ -416,23 +418,31 @@ __global__ void __launch_bounds__(256) tile_normalize_kernel(const uint8_t* canv
         const int c = i / crop, x = i % crop;
         // HF image_transforms: rescale = float32(float64(u8) * (1/255)); normalise = (x - mean) / std in fp32
         const float v = ((float)((double)line[x * 3 + c] * (1.0 / 255.0)) - m[c]) / sdv[c];
-        const size_t o = (((size_t)tile * 3 + c) * crop + y) * crop + x;
+        const size_t o = ((((size_t)blockIdx.y * out_image_crops + tile) * 3 + c) * crop + y) * crop + x;
         if (out_dtype == SLIME_F32) reinterpret_cast<float*>(out)[o] = v;
         else reinterpret_cast<unsigned short*>(out)[o] = to_t1<T>(v);
     }
 }
 
-extern "C" int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3,
-                                    const float* std3, void* out, int out_dtype, void* stream) {
+extern "C" int slime_tile_normalize_batched(const uint8_t* canvas, int images, long canvas_image_stride, int Hc, int Wc,
+                                            int crop, const float* mean3, const float* std3, void* out,
+                                            long out_image_crops, int out_dtype, void* stream) {
     SLIME_REQUIRE(canvas && out && mean3 && std3, "tile_normalize: null pointer (mean3/std3 are HOST pointers)");
     SLIME_REQUIRE(crop > 0 && Hc % crop == 0 && Wc % crop == 0, "tile_normalize: canvas %dx%d is not a multiple of %d", Hc, Wc, crop);
+    SLIME_REQUIRE(images > 0 && images <= 65535, "tile_normalize: %d images", images);
     const int tiles = (Hc / crop) * (Wc / crop);
+    SLIME_REQUIRE(images == 1 || out_image_crops >= tiles, "tile_normalize: out_image_crops %ld < %d tiles", out_image_crops, tiles);
     const float3 mean = make_float3(mean3[0], mean3[1], mean3[2]);
     const float3 istd = make_float3(std3[0], std3[1], std3[2]);
-    const dim3 grid(tiles * crop), block(256);
+    const dim3 grid(tiles * crop, images), block(256);
     const size_t lds = (size_t)crop * 3;
-    if (out_dtype == SLIME_F16) hipLaunchKernelGGL((tile_normalize_kernel<F16>), grid, block, lds, (hipStream_t)stream, canvas, Hc, Wc, crop, mean, istd, out, out_dtype);
-    else hipLaunchKernelGGL((tile_normalize_kernel<BF16>), grid, block, lds, (hipStream_t)stream, canvas, Hc, Wc, crop, mean, istd, out, out_dtype);
+    if (out_dtype == SLIME_F16) hipLaunchKernelGGL((tile_normalize_kernel<F16>), grid, block, lds, (hipStream_t)stream, canvas, canvas_image_stride, Hc, Wc, crop, mean, istd, out, out_image_crops, out_dtype);
+    else hipLaunchKernelGGL((tile_normalize_kernel<BF16>), grid, block, lds, (hipStream_t)stream, canvas, canvas_image_stride, Hc, Wc, crop, mean, istd, out, out_image_crops, out_dtype);
     SLIME_CHECK_LAUNCH("tile_normalize");
     return SLIME_OK;
+}
+
+extern "C" int slime_tile_normalize(const uint8_t* canvas, int Hc, int Wc, int crop, const float* mean3,
+                                    const float* std3, void* out, int out_dtype, void* stream) {
+    return slime_tile_normalize_batched(canvas, 1, 0, Hc, Wc, crop, mean3, std3, out, 0, out_dtype, stream);
 }

@@ -29,13 +29,14 @@ __device__ __forceinline__ uint8_t clip8(int acc) {
 // segment needs ([xmin(first), xmin(last)+count(last)) x 3), fetched 16 B per lane; spans that do not fit
 // (extreme down-scales) are read from global memory directly.
 constexpr int SEG = 256, SPAN_BYTES = 48 * 1024;
-__global__ void __launch_bounds__(256) resample_h_kernel(const uint8_t* __restrict__ src, long src_stride, int src_w,
-                                                         const uint8_t* src_begin, const uint8_t* src_end,
-                                                         uint8_t* __restrict__ dst, long dst_stride, int out_w,
+__global__ void __launch_bounds__(256) resample_h_kernel(const uint8_t* __restrict__ src, long src_image_stride, long src_stride,
+                                                         int src_w, const uint8_t* src_begin, const uint8_t* src_end,
+                                                         uint8_t* __restrict__ dst, long dst_image_stride, long dst_stride, int out_w,
                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
     __shared__ __attribute__((aligned(16))) uint8_t span[SPAN_BYTES];
     const int y = blockIdx.y, x0 = blockIdx.x * SEG, x1 = min(x0 + SEG, out_w) - 1;
-    const uint8_t* row = src + (size_t)y * src_stride;
+    const uint8_t* row = src + (size_t)blockIdx.z * src_image_stride + (size_t)y * src_stride;
+    dst += (size_t)blockIdx.z * dst_image_stride;
     const int first = bounds[2 * x0], last = bounds[2 * x1] + bounds[2 * x1 + 1];     // source pixels [first, last)
     // stage [g0, g1): g0 = the 16-B aligned address at or below the first needed byte (absolute alignment: rows of
     // a packed RGB image are not 16-B aligned themselves)
@@ -78,12 +79,14 @@ __global__ void __launch_bounds__(256) resample_h_kernel(const uint8_t* __restri
 
 // Vertical pass: a thread owns 4 consecutive bytes of an output row (x*3+c is just a byte column for this
 // pass), taps walk down the source rows -> every load/store of a wave is one contiguous 256-B segment.
-__global__ void __launch_bounds__(256) resample_v_kernel(const uint8_t* __restrict__ src, long src_stride,
-                                                         uint8_t* __restrict__ dst, long dst_stride, int row_bytes,
+__global__ void __launch_bounds__(256) resample_v_kernel(const uint8_t* __restrict__ src, long src_image_stride, long src_stride,
+                                                         uint8_t* __restrict__ dst, long dst_image_stride, long dst_stride, int row_bytes,
                                                          const int* __restrict__ bounds, const int* __restrict__ kk, int ksize) {
     const int y = blockIdx.y;
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (c >= row_bytes) return;
+    src += (size_t)blockIdx.z * src_image_stride;
+    dst += (size_t)blockIdx.z * dst_image_stride;
     const int ymin = bounds[2 * y], cnt = bounds[2 * y + 1];
     const int* k = kk + (size_t)y * ksize;
     int s[4];
@@ -151,12 +154,13 @@ extern "C" int slime_resample_coeffs(int in_size, int out_size, int* bounds, int
     return SLIME_OK;
 }
 
-extern "C" int slime_resize_bicubic_u8(const uint8_t* src, int src_h, int src_w, long src_stride, uint8_t* dst,
-                                       long dst_stride, int out_h, int out_w, const int* bounds_h, const int* kk_h,
-                                       int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v, uint8_t* tmp,
-                                       size_t tmp_bytes, void* stream_) {
+extern "C" int slime_resize_bicubic_u8_batched(const uint8_t* src, int images, long src_image_stride, int src_h, int src_w,
+                                               long src_stride, uint8_t* dst, long dst_image_stride, long dst_stride, int out_h,
+                                               int out_w, const int* bounds_h, const int* kk_h, int ksize_h, const int* bounds_v,
+                                               const int* kk_v, int ksize_v, uint8_t* tmp, size_t tmp_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SLIME_REQUIRE(src && dst && src_h > 0 && src_w > 0 && out_h > 0 && out_w > 0, "resize_bicubic_u8: bad arguments");
+    SLIME_REQUIRE(images > 0 && images <= 65535, "resize_bicubic_u8: %d images", images);
     SLIME_REQUIRE(src_stride >= (long)src_w * 3 && dst_stride >= (long)out_w * 3, "resize_bicubic_u8: row stride smaller than a row");
     const bool need_h = out_w != src_w, need_v = out_h != src_h;
     SLIME_REQUIRE(!need_h || (bounds_h && kk_h && ksize_h == slime_resample_ksize(src_w, out_w)),
@@ -164,29 +168,43 @@ extern "C" int slime_resize_bicubic_u8(const uint8_t* src, int src_h, int src_w,
     SLIME_REQUIRE(!need_v || (bounds_v && kk_v && ksize_v == slime_resample_ksize(src_h, out_h)),
                   "resize_bicubic_u8: vertical tables missing or ksize %d != %d", ksize_v, slime_resample_ksize(src_h, out_h));
     if (!need_h && !need_v) {
-        hipError_t e = hipMemcpy2DAsync(dst, dst_stride, src, src_stride, (size_t)src_w * 3, src_h, hipMemcpyDeviceToDevice, stream);
-        if (e != hipSuccess) { slime_set_error("resize_bicubic_u8: copy: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        for (int b = 0; b < images; ++b) {
+            hipError_t e = hipMemcpy2DAsync(dst + (size_t)b * dst_image_stride, dst_stride, src + (size_t)b * src_image_stride, src_stride,
+                                            (size_t)src_w * 3, src_h, hipMemcpyDeviceToDevice, stream);
+            if (e != hipSuccess) { slime_set_error("resize_bicubic_u8: copy: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        }
         return SLIME_OK;
     }
     const uint8_t* vsrc = src;
-    long vstride = src_stride;
+    long vstride = src_stride, vimg = src_image_stride;
     if (need_h) {
         uint8_t* hdst = need_v ? tmp : dst;
         const long hstride = need_v ? (long)out_w * 3 : dst_stride;
-        if (need_v) SLIME_REQUIRE(tmp && tmp_bytes >= (size_t)src_h * out_w * 3, "resize_bicubic_u8: tmp needs %zu bytes", (size_t)src_h * out_w * 3);
-        dim3 grid((out_w + SEG - 1) / SEG, src_h);
-        hipLaunchKernelGGL(resample_h_kernel, grid, dim3(256), 0, stream, src, src_stride, src_w, src, src + (size_t)(src_h - 1) * src_stride + (size_t)src_w * 3, hdst, hstride, out_w,
-                           bounds_h, kk_h, ksize_h);
+        const long himg = need_v ? (long)src_h * out_w * 3 : dst_image_stride;
+        if (need_v) SLIME_REQUIRE(tmp && tmp_bytes >= (size_t)images * src_h * out_w * 3, "resize_bicubic_u8: tmp needs %zu bytes", (size_t)images * src_h * out_w * 3);
+        dim3 grid((out_w + SEG - 1) / SEG, src_h, images);
+        const uint8_t* src_end = src + (size_t)(images - 1) * src_image_stride + (size_t)(src_h - 1) * src_stride + (size_t)src_w * 3;
+        hipLaunchKernelGGL(resample_h_kernel, grid, dim3(256), 0, stream, src, src_image_stride, src_stride, src_w, src, src_end, hdst, himg,
+                           hstride, out_w, bounds_h, kk_h, ksize_h);
         SLIME_CHECK_LAUNCH("resample_h");
         vsrc = hdst;
         vstride = hstride;
+        vimg = himg;
     }
     if (need_v) {
         const int row_bytes = out_w * 3;
-        dim3 grid((row_bytes + 1023) / 1024, out_h);
-        hipLaunchKernelGGL(resample_v_kernel, grid, dim3(256), 0, stream, vsrc, vstride, dst, dst_stride, row_bytes,
+        dim3 grid((row_bytes + 1023) / 1024, out_h, images);
+        hipLaunchKernelGGL(resample_v_kernel, grid, dim3(256), 0, stream, vsrc, vimg, vstride, dst, dst_image_stride, dst_stride, row_bytes,
                            bounds_v, kk_v, ksize_v);
         SLIME_CHECK_LAUNCH("resample_v");
     }
     return SLIME_OK;
+}
+
+extern "C" int slime_resize_bicubic_u8(const uint8_t* src, int src_h, int src_w, long src_stride, uint8_t* dst,
+                                       long dst_stride, int out_h, int out_w, const int* bounds_h, const int* kk_h,
+                                       int ksize_h, const int* bounds_v, const int* kk_v, int ksize_v, uint8_t* tmp,
+                                       size_t tmp_bytes, void* stream) {
+    return slime_resize_bicubic_u8_batched(src, 1, 0, src_h, src_w, src_stride, dst, 0, dst_stride, out_h, out_w, bounds_h, kk_h, ksize_h,
+                                           bounds_v, kk_v, ksize_v, tmp, tmp_bytes, stream);
 }

@@ -159,7 +159,35 @@ def process_images_gpu(images, image_processor, model_cfg, device, dtype=torch.f
     if mode != "anyres":
         raise NotImplementedError(f"process_images_gpu implements image_aspect_ratio='anyres' only (got {mode!r}); "
                                   "use process_images for the other modes")
-    out = [process_anyres_image_gpu(im, image_processor, model_cfg.image_grid_pinpoints, device, dtype) for im in images]
+    _parse_pinpoints(model_cfg.image_grid_pinpoints)
+    arrs = [torch.from_numpy(np.array(im.convert("RGB"))) if isinstance(im, Image.Image) else im for im in images]
+    if len(arrs) > 1 and all(a.shape == arrs[0].shape for a in arrs):
+        # one resolution bucket: the whole batch goes through the slicer in 6 launches (2 resizes x 2 passes, 2 tile+normalise)
+        from . import ops
+        batch = torch.empty((len(arrs),) + tuple(arrs[0].shape), dtype=torch.uint8, device=device)   # [B, H, W, 3]
+        for i, a in enumerate(arrs):
+            batch[i].copy_(a, non_blocking=True)            # straight from the caller's (ideally pinned) buffers
+        B, H, W, _ = batch.shape
+        crop = image_processor.crop_size["height"]
+        tw, th = select_best_resolution_uhd((W, H), (crop, crop))
+        sw, sh = tw / W, th / H
+        if sw < sh:
+            nw, nh = tw, min(math.ceil(H * sw), th)
+        else:
+            nh, nw = th, min(math.ceil(W * sh), tw)
+        n_local = (tw // crop) * (th // crop)
+        thumbs = ops.resize_bicubic_u8_batched(batch, crop, crop)
+        if (nw, nh) == (W, H) == (tw, th):
+            canvas = batch                                 # already a whole number of crops: Pillow's resize is a copy
+        else:
+            canvas = torch.zeros((B, th, tw, 3), dtype=torch.uint8, device=batch.device)
+            x0, y0 = (tw - nw) // 2, (th - nh) // 2
+            ops.resize_bicubic_u8_batched(batch, nw, nh, out=canvas[:, y0:y0 + nh, x0:x0 + nw])
+        out = torch.empty((B, 1 + n_local, 3, crop, crop), dtype=dtype, device=batch.device)
+        ops.tile_normalize_batched(thumbs, crop, image_processor.image_mean, image_processor.image_std, out, 0)
+        ops.tile_normalize_batched(canvas, crop, image_processor.image_mean, image_processor.image_std, out, 1)
+        return out
+    out = [process_anyres_image_gpu(a, image_processor, model_cfg.image_grid_pinpoints, device, dtype) for a in arrs]
     if all(x.shape == out[0].shape for x in out):
         return torch.stack(out, dim=0)
     return out

@@ -472,6 +472,49 @@ def resize_bicubic_u8(img_u8: torch.Tensor, out_w: int, out_h: int, out: Optiona
     return out
 
 
+def resize_bicubic_u8_batched(imgs_u8: torch.Tensor, out_w: int, out_h: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batched :func:`resize_bicubic_u8`: uint8 [B, H, W, 3] -> [B, out_h, out_w, 3], one launch per pass for the
+    whole batch.  ``out`` may be the interior view canvas[:, y0:y0+out_h, x0:x0+out_w] of a [B, Hc, Wc, 3] buffer."""
+    lib = _lib.load()
+    _require_cuda(imgs_u8, "images")
+    if imgs_u8.dtype != torch.uint8 or imgs_u8.dim() != 4 or imgs_u8.shape[3] != 3:
+        raise ValueError(f"resize_bicubic_u8_batched expects uint8 [B, H, W, 3], got {imgs_u8.dtype} {tuple(imgs_u8.shape)}")
+    imgs_u8 = imgs_u8.contiguous()
+    B, H, W, _ = imgs_u8.shape
+    if out is None:
+        out = torch.empty((B, out_h, out_w, 3), dtype=torch.uint8, device=imgs_u8.device)
+    elif (tuple(out.shape) != (B, out_h, out_w, 3) or out.stride(3) != 1 or out.stride(2) != 3 or out.dtype != torch.uint8):
+        raise ValueError("resize_bicubic_u8_batched: out must be a uint8 [B, out_h, out_w, 3] view with packed pixels")
+    bh = kh = bv = kv = None
+    ksh = ksv = 0
+    if W != out_w:
+        bh, kh, ksh = _device_tables(W, out_w, imgs_u8.device)
+    if H != out_h:
+        bv, kv, ksv = _device_tables(H, out_h, imgs_u8.device)
+    tmp = torch.empty((B * H * out_w * 3,), dtype=torch.uint8, device=imgs_u8.device) if (bh is not None and bv is not None) else None
+    _lib.check(lib.slime_resize_bicubic_u8_batched(imgs_u8.data_ptr(), B, imgs_u8.stride(0), H, W, imgs_u8.stride(1), out.data_ptr(),
+                                                   out.stride(0), out.stride(1), out_h, out_w, _ptr(bh), _ptr(kh), ksh, _ptr(bv),
+                                                   _ptr(kv), ksv, _ptr(tmp), 0 if tmp is None else tmp.numel(), _stream()),
+               "slime_resize_bicubic_u8_batched")
+    return out
+
+
+def tile_normalize_batched(canvas_u8: torch.Tensor, crop: int, mean, std, out: torch.Tensor, first_crop: int) -> None:
+    """uint8 [B, Hc, Wc, 3] canvases -> normalised tiles written into out[b, first_crop + tile] of a
+    [B, crops_per_image, 3, crop, crop] tensor (contiguous)."""
+    lib = _lib.load()
+    _require_cuda(canvas_u8, "canvas")
+    canvas_u8 = canvas_u8.contiguous()
+    B, Hc, Wc, _ = canvas_u8.shape
+    tiles = (Hc // crop) * (Wc // crop)
+    assert out.is_contiguous() and out.dim() == 5 and out.shape[0] == B and first_crop + tiles <= out.shape[1]
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    s = (C.c_float * 3)(*[float(v) for v in std])
+    base = out.data_ptr() + first_crop * 3 * crop * crop * out.element_size()
+    _lib.check(lib.slime_tile_normalize_batched(canvas_u8.data_ptr(), B, canvas_u8.stride(0), Hc, Wc, crop, m, s, base, out.shape[1],
+                                                dtype_code(out.dtype), _stream()), "slime_tile_normalize_batched")
+
+
 def router_scores(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
     """Cosine router scores [T] (fp32) for local tokens [T,H] against text embeddings [L,H]."""
     lib = _lib.load()

@@ -90,3 +90,33 @@ def test_device_slicer_matches_reference_goldens(dev):
         flat = out.reshape(out.shape[0], -1).double()
         assert np.array_equal(flat[:, g["sample_idx"]].float().numpy(), g[f"img{i}_anyres_samples"]), i
         assert np.allclose(flat.sum(1).numpy(), g[f"img{i}_anyres_sum"], rtol=0, atol=1e-6), i
+
+
+@pytest.mark.parametrize("size", [(672, 672), (640, 480), (1344, 1344), (300, 200), (1920, 1080)])
+def test_batched_device_slicer_equals_host(dev, size):
+    """process_images_gpu on a uniform batch (6 launches for the whole batch) == process_images (PIL), bit for bit."""
+    from slime_amd import mm_utils as M
+    from slime_amd.image_processor import ClipImageProcessor
+    w, h = size
+    cfg = SimpleNamespace(image_aspect_ratio="anyres", image_grid_pinpoints=PIN)
+    imgs = [Image.fromarray(np.random.default_rng(w + 13 * i).integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB") for i in range(3)]
+    proc = ClipImageProcessor()
+    ref = M.process_images(imgs, proc, cfg)
+    got = M.process_images_gpu(imgs, proc, cfg, dev)
+    assert got.shape == ref.shape and torch.equal(got.cpu(), ref)
+    got16 = M.process_images_gpu([torch.from_numpy(np.array(im)).to(dev) for im in imgs], proc, cfg, dev, torch.bfloat16)
+    assert torch.equal(got16.cpu(), ref.to(torch.bfloat16))
+
+
+def test_mixed_sizes_and_modes(dev):
+    from slime_amd import mm_utils as M
+    from slime_amd.image_processor import ClipImageProcessor
+    cfg = SimpleNamespace(image_aspect_ratio="anyres", image_grid_pinpoints=PIN)
+    proc = ClipImageProcessor()
+    imgs = [Image.fromarray(np.random.default_rng(i).integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
+            for i, (w, h) in enumerate([(672, 672), (1344, 1344)])]
+    ref = M.process_images(imgs, proc, cfg)
+    got = M.process_images_gpu(imgs, proc, cfg, dev)
+    assert isinstance(got, list) and len(got) == 2 and all(torch.equal(g.cpu(), r) for g, r in zip(got, ref))
+    with pytest.raises(NotImplementedError):
+        M.process_images_gpu(imgs, proc, SimpleNamespace(image_aspect_ratio="pad", image_grid_pinpoints=PIN), dev)
