@@ -67,9 +67,9 @@ def event_time_ms(fn, iters=10, warm=2):
 
 # kernel id in the tower driver (include/slime_hip.h: slime_probe) -> (label, rocprof kernel name, N, K)
 PROBE_KERNELS = {
-    1: ("qkv_proj", "gemm_pp_kernel<BF16, 0, 0, 0, 3>", 3072, 1024),
+    1: ("qkv_proj", "gemm_w4_kernel<BF16, 0, 0, 6>", 3072, 1024),
     3: ("out_proj+residual", "gemm_pp_kernel<BF16, 4, 0, 0, 4>", 1024, 1024),
-    5: ("fc1+quick_gelu", "gemm_pp_kernel<BF16, 1, 0, 0, 4>", 4096, 1024),
+    5: ("fc1+quick_gelu", "gemm_w4_kernel<BF16, 1, 0, 8>", 4096, 1024),
     6: ("fc2+residual", "gemm_pp_kernel<BF16, 4, 1, 0, 4>", 1024, 4096),
     2: ("attention", "attn64_kernel<BF16>", 0, 0),
 }

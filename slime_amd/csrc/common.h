@@ -30,6 +30,11 @@ struct BF16 {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
     }
+    // accumulator pinned to the AGPR file (written out: the register allocator otherwise migrates large accumulator
+    // sets between the two files around loop back edges)
+    static __device__ __forceinline__ void mfma16_agpr(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // RNE
@@ -46,6 +51,9 @@ struct F16 {
     static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mfma16_agpr(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};

@@ -20,6 +20,7 @@
 //
 // Epilogues: bias -> T; bias+quick-GELU -> T; bias+erf-GELU -> T; bias -> fp32; fp32 += (residual).
 #include "common.h"
+#include <type_traits>
 
 struct GemmArgs {
     const char* A; const char* B; const float* bias; void* C;
@@ -526,6 +527,179 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             d[0] = t_start; d[1] = t_pro; d[2] = t_loop; d[3] = __builtin_amdgcn_s_memtime();
         }
     }
+}
+
+
+// ================================================================================================
+// Stream kernel (256 x 256 x 64 tile, FOUR waves, each owning a 128 x 128 quarter in 256 accumulator
+// registers).  What tools/mfma_mem_mix.hip measured on this chip: a wave that interleaves its LDS-DMA issues and
+// fragment ds_reads one at a time between back-to-back MFMAs -- no L/M phase split, no barrier in between -- runs
+// at 1.10x the bare MFMA time at this kernel's ratio (4 DMA + 8 ds_read_b128 per 32 MFMAs), whereas the
+// ping-pong kernel's slot structure leaves the matrix pipe idle ~40 % of its main loop (barrier pairs around
+// every 16 MFMAs; an L section is as long as an M section).  So here:
+//   * per-wave tile 128 x 128: 16 fragment reads per 64 MFMAs (0.25 / MFMA instead of 0.375), 16 DMA pieces per
+//     k-tile per wave;
+//   * one in-order instruction stream per SIMD: MFMA, MFMA, MFMA + {one ds_read for the NEXT k-step, one DMA piece
+//     for the k-tile AFTER next}; fragments are register double buffered (2 x 16 x 4 VGPRs), accumulators live in
+//     AGPRs;
+//   * ONE workgroup barrier per k-tile (between its two k-steps): it publishes k-tile t+1 (every wave has waited for
+//     its own pieces) and retires the reads of k-tile t, after which the stage is refilled with k-tile t+2.
+// LDS image, swizzles, weight-row permutation and epilogue are those of the ping-pong kernel.
+// ================================================================================================
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128_imm(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
+template <typename T, int EPI, int KTAG, int MI>
+__global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
+    // MI = 16-row MFMA tiles per wave along M: 8 -> 256 x 256 workgroup tile (256 accumulator registers per lane),
+    // 6 -> 192 x 256 (192 accumulators: leaves the register allocator slack, and quantises 11540-row grids better).
+    constexpr int WM = 16 * MI, BM = 2 * WM, BN = 256, BK = 64, NF = MI + 8;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
+    constexpr int A_PIECES = BM / 8 / 4, NP = A_PIECES + 8;         // DMA pieces per wave per k-tile (A, then 8 of B)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 4;
+    const int in_group = GROUP_M * tiles_n;
+    const int first_m = (pid / in_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % in_group) % gsz;
+    const int tn = (pid % in_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // ---- DMA pieces of this wave: A pieces wave, wave+4, ... (8 rows each), B pieces likewise ----
+    unsigned soff[NP];
+#pragma unroll
+    for (int j = 0; j < A_PIECES; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        const int rl = min(row, g.M - 1 - m0);                       // clamp: rows past M re-read the last row
+        soff[j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rho = (wave + 4 * j) * 8 + lrow;                   // LDS row of the weight tile
+        const int nl = rho & 15;
+        const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
+        soff[A_PIECES + j] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+    }
+    const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
+    const char* b_gbase = g.B + (size_t)n0 * g.K * 2;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem));
+    auto dma = [&](int j, int tile) {                                // piece j (0..NP-1) of k-tile `tile`
+        const bool isA = j < A_PIECES;
+        const char* gb = uniform_ptr((isA ? a_gbase : b_gbase) + (size_t)tile * (BK * 2));
+        const unsigned dst = lds0 + (tile & 1) * STAGE + (isA ? (wave + 4 * j) * 1024 : A_BYTES + (wave + 4 * (j - A_PIECES)) * 1024);
+        lds_dma16(soff[j], gb, dst);
+    };
+
+    // ---- fragment read bases (stage 0); the stage offset is added per k-tile ----
+    int xb[2], wb[2];                                                // byte offsets inside smem
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sw = ((ks * 4 + lq) ^ (lane & 7)) << 4;
+        xb[ks] = (wm * WM + li) * 128 + sw;
+        wb[ks] = A_BYTES + (wn * 128 + li) * 128 + sw;
+    }
+
+    f32x4 acc[MI][8];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    // ---- prologue ----
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dma(j, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) dma(j, 1);
+        if constexpr (NP == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 F[2][NF];                                                  // [buffer][0..MI-1 = X (m tiles), MI.. = W (n tiles)]
+    // Fragment reads are ordinary LDS loads (the compiler tracks lgkmcnt per register and places counted waits); the
+    // LDS-DMA is inline asm with a memory clobber, so it neither triggers conservative vmcnt(0) guards nor lets the
+    // loads be cached across it.
+    auto read_frag = [&](u32x4& dstF, int i, int xbase, int wbase) {
+        dstF = *reinterpret_cast<const u32x4*>(smem + (i < MI ? xbase + i * 2048 : wbase + (i - MI) * 2048));
+    };
+    // One k-step: 8*MI MFMAs on `cur`; every third MFMA is followed by one fragment read into `nxt` (READS) and one DMA
+    // piece of k-tile `dma_tile` (DMA).  READS / DMA are compile-time so the stream has no branches.
+    auto kstep = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], auto reads, int xbase, int wbase, auto dmas, int dma_tile) {
+#pragma unroll
+        for (int m = 0; m < 8 * MI; ++m) {
+            const int mi = m % MI, nj = m / MI;
+            T::mfma16_agpr(acc[mi][nj], cur[MI + nj], cur[mi]);
+            if constexpr (decltype(reads)::value) {
+                if (m % 3 == 1 && m / 3 < NF) read_frag(nxt[m / 3], m / 3, xbase, wbase);
+            }
+            if constexpr (decltype(dmas)::value) {
+                if (m % 3 == 2 && m / 3 < NP) dma(m / 3, dma_tile);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    auto tile_body = [&](int t, auto more, auto refill) {
+        const int so = (t & 1) * STAGE, sn = ((t + 1) & 1) * STAGE;
+        // k-step 0 of tile t: prefetch the k-step 1 fragments of the same stage
+        kstep(F[0], F[1], Yes{}, xb[1] + so, wb[1] + so, No{}, 0);
+        // publish tile t+1 / retire the reads of tile t
+        if constexpr (decltype(more)::value) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // k-step 1 of tile t: prefetch (t+1, k-step 0), refill this stage with tile t+2
+        kstep(F[1], F[0], more, xb[0] + sn, wb[0] + sn, refill, t + 2);
+    };
+
+    // fragments of (tile 0, k-step 0)
+#pragma unroll
+    for (int i = 0; i < NF; ++i) read_frag(F[0][i], i, xb[0], wb[0]);
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile_body(t, Yes{}, Yes{});
+    if (t + 1 < nk) { tile_body(t, Yes{}, No{}); ++t; }
+    tile_body(t, No{}, No{});
+
+    // the MFMAs are inline asm, so the compiler does not know their results need the matrix pipe's write-back latency
+    // before a VALU instruction may read them: pad by hand (>= 18 wait states for a 16x16x32 MFMA)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    // ... and tie every accumulator to a statement after the padding (volatile asm statements keep their order), so the
+    // epilogue's v_accvgpr_read cannot be scheduled in front of it
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
+    if (m0 + BM <= g.M) epilogue_wave<T, EPI, MI, 8, true>(g, acc, m0 + wm * WM + li, n0 + wn * 128 + 8 * lq);
+    else epilogue_wave<T, EPI, MI, 8, false>(g, acc, m0 + wm * WM + li, n0 + wn * 128 + 8 * lq);
 }
 
 
@@ -1065,6 +1239,28 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0>(g, stream) : launch_pp_k<T, EPI, 0, 0>(g, stream);
 }
 
+template <typename T, int EPI, int KTAG, int MI>
+static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
+    constexpr int BM = 32 * MI;
+    constexpr int LDS = 2 * (BM + 256) * 64 * 2;
+    auto kern = gemm_w4_kernel<T, EPI, KTAG, MI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) { slime_set_error("gemm_w4: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
+        attr_set = true;
+    }
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
+    SLIME_CHECK_LAUNCH("gemm_w4");
+    return SLIME_OK;
+}
+
+template <typename T, int EPI, int MI>
+static int launch_w4(const GemmArgs& g, hipStream_t stream) {
+    return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
+}
+
 template <typename T, int EPI>
 static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0, 3>(g, stream) : launch_pp_k<T, EPI, 0, 0, 3>(g, stream);
@@ -1092,7 +1288,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
 // covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
 // running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong (auto picks 4 or 9), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
+static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 = 192x256 / 256x256 four-wave stream kernel (auto: 4 for sub-round grids, else 10 or 11), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
 static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
@@ -1120,7 +1316,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             const long n256 = ((g.M + 255) / 256) * tn, n192 = ((g.M + 191) / 192) * tn;
             const long c256 = (n256 + 255) / 256 * (256 + 40);
             const long c192 = (n192 + 255) / 256 * (192 + 40);
-            if (n256 >= 256 && c192 < c256) tile = 9;
+            // ... and multi-round grids run the four-wave stream kernel (same-box A/B inside the two-stream tower: fc1 and
+            // qkv on the stream kernel 16.45 -> 15.72 ms; out_proj / fc2 on it lose 0.1-0.3 ms, they stay ping-pong)
+            if (n256 >= 256) tile = c192 < c256 ? 10 : 11;
         }
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
@@ -1134,6 +1332,8 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 5) return launch_ppp<T, EPI>(g, stream);
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 9) return launch_pp192<T, EPI>(g, stream);
+    if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
+    if (tile == 11) return launch_w4<T, EPI, 8>(g, stream);
     if (g_sched == 0) {
         switch (tile) {
             case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream);
