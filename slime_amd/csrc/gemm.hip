@@ -554,8 +554,10 @@ __device__ __forceinline__ u32x4 lds_read_b128_imm(unsigned addr) {
     return r;
 }
 
-template <typename T, int EPI, int KTAG, int MI>
+template <typename T, int EPI, int KTAG, int MI, int ABL = 0>
 __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
+    // ABL (timing ablations only, wrong results): bit0 = no LDS-DMA in the main loop, bit1 = no fragment reads in the
+    // main loop, bit2 = no barrier in the main loop.
     // MI = 16-row MFMA tiles per wave along M: 8 -> 256 x 256 workgroup tile (256 accumulator registers per lane),
     // 6 -> 192 x 256 (192 accumulators: leaves the register allocator slack, and quantises 11540-row grids better).
     constexpr int WM = 16 * MI, BM = 2 * WM, BN = 256, BK = 64, NF = MI + 8;
@@ -654,10 +656,10 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
         for (int m = 0; m < 8 * MI; ++m) {
             const int mi = m % MI, nj = m / MI;
             T::mfma16_agpr(acc[mi][nj], cur[MI + nj], cur[mi]);
-            if constexpr (decltype(reads)::value) {
+            if constexpr (decltype(reads)::value && !(ABL & 2)) {
                 if (m % 3 == 1 && m / 3 < NF) read_frag(nxt[m / 3], m / 3, xbase, wbase);
             }
-            if constexpr (decltype(dmas)::value) {
+            if constexpr (decltype(dmas)::value && !(ABL & 1)) {
                 if (m % 3 == 2 && m / 3 < NP) dma(m / 3, dma_tile);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -670,7 +672,7 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
         // k-step 0 of tile t: prefetch the k-step 1 fragments of the same stage
         kstep(F[0], F[1], Yes{}, xb[1] + so, wb[1] + so, No{}, 0);
         // publish tile t+1 / retire the reads of tile t
-        if constexpr (decltype(more)::value) {
+        if constexpr (decltype(more)::value && !(ABL & 4)) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
@@ -1239,11 +1241,11 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0>(g, stream) : launch_pp_k<T, EPI, 0, 0>(g, stream);
 }
 
-template <typename T, int EPI, int KTAG, int MI>
+template <typename T, int EPI, int KTAG, int MI, int ABL = 0>
 static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MI;
     constexpr int LDS = 2 * (BM + 256) * 64 * 2;
-    auto kern = gemm_w4_kernel<T, EPI, KTAG, MI>;
+    auto kern = gemm_w4_kernel<T, EPI, KTAG, MI, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1258,6 +1260,16 @@ static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
 
 template <typename T, int EPI, int MI>
 static int launch_w4(const GemmArgs& g, hipStream_t stream) {
+    if constexpr (EPI == SLIME_EPI_BIAS_T && T::id == SLIME_BF16 && MI == 8) {     // ablation builds: one configuration only
+        switch (g_ablation) {
+            case 1: return launch_w4_k<T, EPI, 0, MI, 1>(g, stream);
+            case 2: return launch_w4_k<T, EPI, 0, MI, 2>(g, stream);
+            case 3: return launch_w4_k<T, EPI, 0, MI, 3>(g, stream);
+            case 4: return launch_w4_k<T, EPI, 0, MI, 4>(g, stream);
+            case 7: return launch_w4_k<T, EPI, 0, MI, 7>(g, stream);
+            default: break;
+        }
+    }
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 

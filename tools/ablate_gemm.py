@@ -12,8 +12,9 @@ def timeit(fn, warm=3, it=20):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e-3
-lib.slime_gemm_force_tile(4)
-for M in (256 * 64, 11540, 23080):          # 64 row tiles: exact rounds for N multiples of 1024
+TILE = int(os.environ.get("TILE", "4"))
+lib.slime_gemm_force_tile(TILE)
+for M in (256 * 64, 11540):          # 64 row tiles: exact rounds for N multiples of 1024
     for N, K in ((4096, 1024), (1024, 4096), (4096, 4096)):
         a = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
         b = torch.randn(N, device=dev); out = torch.zeros(M, N, device=dev, dtype=dt)
