@@ -67,9 +67,9 @@ def event_time_ms(fn, iters=10, warm=2):
 
 # kernel id in the tower driver (include/slime_hip.h: slime_probe) -> (label, rocprof kernel name, N, K)
 PROBE_KERNELS = {
-    1: ("qkv_proj", "gemm_w4_kernel<BF16, 0, 0, 6>", 3072, 1024),
+    1: ("qkv_proj", "gemm_w4_kernel<BF16, 0, 0, 6, 0>", 3072, 1024),
     3: ("out_proj+residual", "gemm_pp_kernel<BF16, 4, 0, 0, 4>", 1024, 1024),
-    5: ("fc1+quick_gelu", "gemm_w4_kernel<BF16, 1, 0, 8>", 4096, 1024),
+    5: ("fc1+quick_gelu", "gemm_w4_kernel<BF16, 1, 0, 8, 0>", 4096, 1024),
     6: ("fc2+residual", "gemm_pp_kernel<BF16, 4, 1, 0, 4>", 1024, 4096),
     2: ("attention", "attn64_kernel<BF16>", 0, 0),
 }
@@ -225,10 +225,14 @@ def main():
         halves = 2 if tower.vision_tower.two_streams else 1
         dom, per = kernel_roofline(tower.vision_tower, pixels[: n_local // halves].contiguous())
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
+        # profiles/README.md); null if that kernel is not in the committed summary
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
         if os.path.isfile(pmc):
             try:
-                traffic = json.load(open(pmc)).get("dominant_gemm_hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(per[dom]["rocprof_name"], {})
+                if "hbm_read_bytes_corrected" in rec and "hbm_write_bytes" in rec:
+                    traffic = int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"])
             except Exception:
                 traffic = None
         res = {
