@@ -138,16 +138,19 @@ class HipCLIPVisionModel(nn.Module):
             self._streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
         cur = torch.cuda.current_stream()
         half = (n + 1) // 2
-        parts, outs = (pixel_values[:half], pixel_values[half:]), []
-        for slot, (s, p) in enumerate(zip(self._streams, parts)):
+        rows = self.config.num_patches + (1 if keep_cls else 0)
+        out = torch.empty((n, rows, self.config.hidden_size), dtype=out_dtype, device=pixel_values.device)
+        parts = ((pixel_values[:half], out[:half]), (pixel_values[half:], out[half:]))
+        for slot, (s, (p, o)) in enumerate(zip(self._streams, parts)):
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                outs.append(ops.tower_forward(self.packed(select_layer, slot), p, out_dtype, keep_cls))
+                ops.tower_forward(self.packed(select_layer, slot), p, out_dtype, keep_cls, out=o)   # both halves land in one tensor
             p.record_stream(s)
-        for s, o in zip(self._streams, outs):
+        out.record_stream(self._streams[0])
+        out.record_stream(self._streams[1])
+        for s in self._streams:
             cur.wait_stream(s)
-            o.record_stream(cur)
-        return torch.cat(outs, dim=0)
+        return out
 
     def forward(self, pixel_values: torch.Tensor, output_hidden_states: bool = False, **_):
         """HF-like call: returns an object with ``hidden_states`` (L+1 entries, computed on demand is

@@ -187,8 +187,9 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
 
 
 def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[torch.dtype] = None,
-                  keep_cls: bool = False, want_hidden: bool = False):
-    """pixels [N,3,S,S] (fp32 or the tower dtype) -> features [N, P(+1), D] in out_dtype."""
+                  keep_cls: bool = False, want_hidden: bool = False, out: Optional[torch.Tensor] = None):
+    """pixels [N,3,S,S] (fp32 or the tower dtype) -> features [N, P(+1), D] in out_dtype (written into ``out`` if given:
+    a contiguous [N, P(+1), D] tensor or leading-dim slice of one)."""
     lib = _lib.load()
     _require_cuda(pixels, "pixels")
     cfg = pt.cfg
@@ -201,7 +202,10 @@ def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[tor
     n = pixels.shape[0]
     out_dtype = out_dtype or pixels.dtype
     rows = cfg.seq_len if keep_cls else cfg.num_patches
-    out = torch.empty((n, rows, cfg.hidden_size), dtype=out_dtype, device=pixels.device)
+    if out is None:
+        out = torch.empty((n, rows, cfg.hidden_size), dtype=out_dtype, device=pixels.device)
+    elif tuple(out.shape) != (n, rows, cfg.hidden_size) or out.dtype != out_dtype or not out.is_contiguous():
+        raise ValueError("tower_forward: out must be a contiguous [N, rows, hidden] tensor of the output dtype")
     hidden = torch.empty((n, cfg.seq_len, cfg.hidden_size), dtype=torch.float32, device=pixels.device) if want_hidden else None
     need = lib.slime_vit_workspace_bytes(C.byref(pt.desc), n)
     ws = pt.ws.get(need, pixels.device)
