@@ -557,7 +557,11 @@ __device__ __forceinline__ u32x4 lds_read_b128_imm(unsigned addr) {
 template <typename T, int EPI, int KTAG, int MI, int ABL = 0>
 __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
     // ABL (timing ablations only, wrong results): bit0 = no LDS-DMA in the main loop, bit1 = no fragment reads in the
-    // main loop, bit2 = no barrier in the main loop.
+    // main loop, bit2 = no barrier in the main loop.  ABL bit3 (results correct): the per-k-tile s_barrier is replaced by a
+    // split barrier on an LDS counter -- a wave ARRIVES 16 MFMAs before the end of k-step 0 (its tile t+1 pieces have landed,
+    // its reads of tile t have returned) and only CHECKS that all four waves have arrived when k-step 1 starts.  Measured
+    // 3-5 % SLOWER than s_barrier (256-row tile; 8-15 % for the 192-row tile): the hardware barrier is cheaper than one LDS
+    // atomic + one polled read per k-tile.  Kept as an ablation (slime_gemm_set_ablation(8), BF16 bias epilogue only).
     // MI = 16-row MFMA tiles per wave along M: 8 -> 256 x 256 workgroup tile (256 accumulator registers per lane),
     // 6 -> 192 x 256 (192 accumulators: leaves the register allocator slack, and quantises 11540-row grids better).
     constexpr int WM = 16 * MI, BM = 2 * WM, BN = 256, BK = 64, NF = MI + 8;
@@ -638,6 +642,10 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    if constexpr ((ABL & 8) != 0) {
+        if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem + 2 * STAGE) = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -651,13 +659,25 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
     };
     // One k-step: 8*MI MFMAs on `cur`; every third MFMA is followed by one fragment read into `nxt` (READS) and one DMA
     // piece of k-tile `dma_tile` (DMA).  READS / DMA are compile-time so the stream has no branches.
-    auto kstep = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], auto reads, int xbase, int wbase, auto dmas, int dma_tile) {
+    constexpr bool SPLIT = (ABL & 8) != 0;
+    constexpr int ARRIVE_AT = 8 * MI - 16;
+    unsigned* sync_cnt = reinterpret_cast<unsigned*>(smem + 2 * STAGE);
+    unsigned polled = 0;
+    auto kstep = [&](u32x4 (&cur)[NF], u32x4 (&nxt)[NF], auto reads, int xbase, int wbase, auto dmas, int dma_tile, auto arrive) {
+        constexpr int RS = decltype(arrive)::value ? 2 : 3;           // an arriving step issues its reads early
 #pragma unroll
         for (int m = 0; m < 8 * MI; ++m) {
             const int mi = m % MI, nj = m / MI;
             T::mfma16_agpr(acc[mi][nj], cur[MI + nj], cur[mi]);
             if constexpr (decltype(reads)::value && !(ABL & 2)) {
-                if (m % 3 == 1 && m / 3 < NF) read_frag(nxt[m / 3], m / 3, xbase, wbase);
+                if (m % RS == 1 && m / RS < NF) read_frag(nxt[m / RS], m / RS, xbase, wbase);
+            }
+            if constexpr (decltype(arrive)::value) {
+                if (m == ARRIVE_AT) {
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(sync_cnt, 1u);
+                }
+                if (m == ARRIVE_AT + 8) polled = *reinterpret_cast<volatile unsigned*>(sync_cnt);
             }
             if constexpr (decltype(dmas)::value && !(ABL & 1)) {
                 if (m % 3 == 2 && m / 3 < NP) dma(m / 3, dma_tile);
@@ -670,16 +690,21 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
     auto tile_body = [&](int t, auto more, auto refill) {
         const int so = (t & 1) * STAGE, sn = ((t + 1) & 1) * STAGE;
         // k-step 0 of tile t: prefetch the k-step 1 fragments of the same stage
-        kstep(F[0], F[1], Yes{}, xb[1] + so, wb[1] + so, No{}, 0);
+        kstep(F[0], F[1], Yes{}, xb[1] + so, wb[1] + so, No{}, 0, std::integral_constant<bool, SPLIT && decltype(more)::value>{});
         // publish tile t+1 / retire the reads of tile t
-        if constexpr (decltype(more)::value && !(ABL & 4)) {
+        if constexpr (decltype(more)::value && SPLIT) {
+            const unsigned target = 4u * (unsigned)(t + 1);
+            int guard = 0;
+            while (__builtin_amdgcn_readfirstlane(polled) < target && ++guard < (1 << 22))
+                polled = *reinterpret_cast<volatile unsigned*>(sync_cnt);
+        } else if constexpr (decltype(more)::value && !(ABL & 4)) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
         // k-step 1 of tile t: prefetch (t+1, k-step 0), refill this stage with tile t+2
-        kstep(F[1], F[0], more, xb[0] + sn, wb[0] + sn, refill, t + 2);
+        kstep(F[1], F[0], more, xb[0] + sn, wb[0] + sn, refill, t + 2, No{});
     };
 
     // fragments of (tile 0, k-step 0)
@@ -1244,7 +1269,7 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
 template <typename T, int EPI, int KTAG, int MI, int ABL = 0>
 static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MI;
-    constexpr int LDS = 2 * (BM + 256) * 64 * 2;
+    constexpr int LDS = 2 * (BM + 256) * 64 * 2 + 64;               // + the split-barrier counter
     auto kern = gemm_w4_kernel<T, EPI, KTAG, MI, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1267,6 +1292,7 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
             case 3: return launch_w4_k<T, EPI, 0, MI, 3>(g, stream);
             case 4: return launch_w4_k<T, EPI, 0, MI, 4>(g, stream);
             case 7: return launch_w4_k<T, EPI, 0, MI, 7>(g, stream);
+            case 8: return launch_w4_k<T, EPI, 0, MI, 8>(g, stream);   // split barrier on an LDS counter (correct results)
             default: break;
         }
     }

@@ -16,12 +16,10 @@ def run():
         with torch.cuda.stream(s): ops.tower_forward(pt, p)
     for s in streams: cur.wait_stream(s)
 SH = {"qkv": (3072, 1024), "out": (1024, 1024), "fc1": (4096, 1024), "fc2": (1024, 4096)}
-CONFIGS = [("auto (pp 4/9)", {}),
-           ("fc1 11", {"fc1": 11}),
-           ("fc1 11 qkv 10", {"fc1": 11, "qkv": 10}),
-           ("fc1 11 qkv 11", {"fc1": 11, "qkv": 11}),
-           ("fc1 11 qkv 10 fc2 11", {"fc1": 11, "qkv": 10, "fc2": 11}),
-           ("fc1 11 qkv 10 out 11", {"fc1": 11, "qkv": 10, "out": 11})]
+CONFIGS = [("auto (fc1 11, qkv 10, out/fc2 pp4)", {}),
+           ("split barrier: fc1 13 qkv 12", {"fc1": 13, "qkv": 12}),
+           ("split barrier: fc1 13", {"fc1": 13}),
+           ("split barrier: fc1 13 qkv 13", {"fc1": 13, "qkv": 13})]
 for _ in range(3): run()
 for rep in range(2):
     for name, cfg in CONFIGS:
