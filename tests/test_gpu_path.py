@@ -128,3 +128,23 @@ def test_tower_rejects_wrong_size(dev, tiny_weights):
     pt = ops.pack_tower(tsd, W.TINY, torch.bfloat16, dev)
     with pytest.raises(ValueError, match="doesn't match model"):
         ops.tower_forward(pt, torch.zeros(1, 3, 224, 224, device=dev))
+
+
+def test_full_size_shard_invariance(dev):
+    """BASELINE config 2 at full ViT-L/14-336 size: the 40-crop tower output (two-stream product path) equals, bit for
+    bit, the concatenation of 8 shards of 5 crops (the 8-GPU layout of SURVEY 8e) and of 2 shards of 20 -- although
+    the shards dispatch to different GEMM kernels (stream kernel, 192/256-row ping-pong tiles) -- and is deterministic
+    from run to run.  This is the size-independent property the multi-GPU all-gather relies on."""
+    from slime_amd import weights as W
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
+    vm = HipCLIPVisionModel(W.CLIP_L_336)
+    vm.load_state_dict(W.make_tower_state_dict(W.CLIP_L_336, seed=1234))
+    vm.to(dev).to(torch.bfloat16)
+    px = W.synthetic_pixels(40, seed=9).to(dev).to(torch.bfloat16)
+    full = vm.encode(px)
+    again = vm.encode(px)
+    assert full.shape == (40, 576, 1024) and torch.isfinite(full.float()).all()
+    assert torch.equal(full, again)
+    for shard in (5, 20):
+        parts = torch.cat([vm.encode(px[i:i + shard].contiguous()) for i in range(0, 40, shard)])
+        assert torch.equal(parts, full), shard
