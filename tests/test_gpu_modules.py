@@ -330,3 +330,27 @@ def test_fused_adapter_full_dims_and_errors(dev):
     assert rel_l2(out[:, 576:].cpu(), ref_l.cpu()) < 1e-6
     with pytest.raises(SlimeHipError, match="grid"):
         ops.adapter_forward(pg, post, feats, B, n, 3, 2, True, -1, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cfg3_layout_17_crops_vs_oracle(dev, dtype):
+    """BASELINE config 3's layout (1 global + 16 local crops on an explicit 4 x 4 grid -- synthetic: the reference slicer
+    never emits more than 7 crops), 2 images, tiny geometry: tower + fused adapter against the oracle's stages."""
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    enc, tsd, asd = _tiny_encoder(dev, dtype)
+    model = enc.get_model()
+    B, n_local, nw, nh = 2, 16, 4, 4
+    px = W.synthetic_pixels(B * (1 + n_local), seed=77)
+    feats = enc.get_vision_tower()(px.to(dev).to(dtype), out_dtype=dtype)                    # [34, 576, 128]
+    tokens = ops.adapter_forward(model.mm_projector.packed(dtype), model.sampler.post_qformer.packed(576, dtype), feats,
+                                 B, n_local, nw, nh, True, -1, torch.float32).cpu()
+    heads = W.ADAPTER_TINY.num_heads
+    for i in range(B):
+        f = O.tower_forward(tsd, W.TINY, px[i * 17:(i + 1) * 17])
+        glob = O.gated_block_forward(W.sub_state(asd, "mm_projector."), f[:1], heads)[0]
+        comp = O.resampler_forward(W.sub_state(asd, "sampler.post_qformer."), f[1:], heads)
+        loc = O.mlp_projector(W.sub_state(asd, "mm_projector."), comp)
+        merged = O.spatial_merge(loc, nw, nh, 12)
+        assert rel_l2(tokens[i, :576], glob) < TOL[dtype] * 1.5
+        assert rel_l2(tokens[i, 576:], merged) < TOL[dtype] * 2
