@@ -3,9 +3,9 @@
 // Both operands are K-contiguous (activations row-major, weights in nn.Linear layout), which is
 // exactly what v_mfma_f32_16x16x32_{bf16,f16} wants: every lane feeds 8 consecutive k.
 //
-// Structure (per workgroup, BM x BN output tile, BK = 64):
+// Common to every kernel in this file (BM x BN output tile per workgroup, BK = 64):
 //   * HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane, no VGPR round trip), two LDS
-//     stages, one barrier per K-tile; the DMA of tile t+1 is in flight while tile t is multiplied.
+//     stages; the DMA of later k-tiles is in flight while the current one is multiplied.
 //   * LDS image is [rows][64] T (128-B rows) with the 16-B chunk index XOR-ed by (row & 7).  LDS-DMA
 //     writes lane-linearly, so the swizzle is applied to the per-lane SOURCE address (each 8-lane
 //     group still reads one full 128-B line) and again on the ds_read_b128 side: conflict-free
@@ -16,7 +16,15 @@
 //     lane) such that two neighbouring MFMA tiles give a lane 8 consecutive columns: 16-B bf16
 //     stores / 32-B fp32 read-modify-writes in the epilogue, bias loaded as float4.
 //   * Block ids are remapped XCD-first (block b runs on XCD b % 8), then GROUP_M-swizzled, so the
-//     32 CUs of an XCD work on an 8 x 4 patch of tiles that share A/B panels through their L2.
+//     32 CUs of an XCD work on a GROUP_M x 8 patch of tiles that share A/B panels through their L2.
+//
+// Kernels (launch_epi picks one; slime_gemm_force_tile overrides for A/B tests):
+//   gemm_w4_kernel   four-wave STREAM kernel, 256x256 / 192x256: reads and DMA interleaved into one MFMA
+//                    stream per SIMD, accumulators in AGPRs, one barrier per k-tile -- grids of >= 256 tiles
+//   gemm_pp_kernel   eight-wave PING-PONG kernel, 256x256 / 192x256 -- sub-round grids (they co-run best
+//                    with the other tower stream's kernels)
+//   gemm_kernel      lock-step kernel, 128x128 (narrow N, tiny M) and 256x256
+//   gemm_ppp_kernel, gemm_pp32b_kernel   persistent / 32x32x16-MFMA ping-pong variants kept as measured alternatives
 //
 // Epilogues: bias -> T; bias+quick-GELU -> T; bias+erf-GELU -> T; bias -> fp32; fp32 += (residual).
 #include "common.h"
