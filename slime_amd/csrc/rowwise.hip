@@ -111,33 +111,53 @@ extern "C" int slime_layernorm(const float* x, int ldx, int rows, int D, const f
 }
 
 // ------------------------------------------------------------------------------------------------
-// im2col: one thread per 8-column chunk of the [n*g*g, kpad] operand; column k = (c, ky, kx).
-// Pixels are tiny (0.7-1.4 MB/crop) and stay L2-resident; the writes are 16 B/lane coalesced.
+// im2col for the patch-embed conv.  One workgroup = one row of patches of one crop: the 3 x patch image rows
+// it needs (3 x 14 rows of 336 pixels = 28 KB in T) are fetched with 16-byte coalesced loads into LDS (fp32
+// pixels are rounded to T on the way), then the [g patches, kpad] operand rows are written 16 B per lane, each
+// element looked up through a k -> (c, ky, kx) table built once per workgroup.  Column k = (c, ky, kx); columns
+// >= 3*patch^2 are the zero padding of the GEMM's K dimension.
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename PixT>
-__global__ void __launch_bounds__(256) im2col_kernel(const PixT* px, unsigned short* out, int n, int image,
-                                                     int patch, int kpad) {
-    const int g = image / patch, pp = patch * patch, kreal = 3 * pp, chunks = kpad / 8;
-    const long total = (long)n * g * g * chunks;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % chunks);
-        const long row = idx / chunks;
-        const int pxi = (int)(row % g), pyi = (int)((row / g) % g), crop = (int)(row / ((long)g * g));
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = ch * 8 + j;
-            if (k < kreal) {
-                const int c = k / pp, r = k % pp, ky = r / patch, kx = r % patch;
-                const size_t off = (((size_t)crop * 3 + c) * image + (pyi * patch + ky)) * image + (pxi * patch + kx);
-                if constexpr (sizeof(PixT) == 4) v[j] = reinterpret_cast<const float*>(px)[off];
-                else {
-                    const unsigned w = reinterpret_cast<const unsigned short*>(px)[off];
-                    v[j] = T::lo(w);     // pixels already in T when 16-bit (checked on the host)
-                }
-            } else v[j] = 0.f;
+__global__ void __launch_bounds__(256) im2col_kernel(const PixT* px, unsigned short* out, int image, int patch, int kpad) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i2c[];
+    unsigned short* tile = reinterpret_cast<unsigned short*>(smem_i2c);              // [3*patch][image]
+    const int g = image / patch, pp = patch * patch, kreal = 3 * pp, nrows = 3 * patch;
+    unsigned short* lut = tile + (size_t)nrows * image;                               // [kpad]: LDS offset of column k, 0xffff = pad
+    const int crop = blockIdx.x / g, pyi = blockIdx.x % g, tid = threadIdx.x;
+
+    for (int k = tid; k < kpad; k += 256) {
+        unsigned short v = 0xffffu;
+        if (k < kreal) { const int c = k / pp, r = k % pp; v = (unsigned short)((c * patch + r / patch) * image + r % patch); }
+        lut[k] = v;
+    }
+    constexpr int EPC = 16 / (int)sizeof(PixT);                                       // pixels per 16-byte chunk
+    const int cpr = image / EPC;                                                      // chunks per image row
+    for (int i = tid; i < nrows * cpr; i += 256) {
+        const int r = i / cpr, q = i % cpr, c = r / patch, ky = r % patch;
+        const PixT* src = px + (((size_t)crop * 3 + c) * image + (size_t)pyi * patch + ky) * image + (size_t)q * EPC;
+        unsigned short* dst = tile + (size_t)r * image + q * EPC;
+        if constexpr (sizeof(PixT) == 4) {
+            const float4 f = *reinterpret_cast<const float4*>(src);
+            u32x2 w = {T::pack2(f.x, f.y), T::pack2(f.z, f.w)};
+            *reinterpret_cast<u32x2*>(dst) = w;
+        } else {
+            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);    // pixels already in T (checked on the host)
         }
-        *reinterpret_cast<u32x4*>(out + row * kpad + ch * 8) = pack8<T>(v);
+    }
+    __syncthreads();
+    const int chunks = kpad / 8;
+    unsigned short* orow = out + ((size_t)crop * g * g + (size_t)pyi * g) * kpad;
+    for (int i = tid; i < g * chunks; i += 256) {
+        const int pxi = i / chunks, ch = i % chunks;
+        unsigned w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned short o0 = lut[ch * 8 + 2 * j], o1 = lut[ch * 8 + 2 * j + 1];
+            const unsigned lo = o0 == 0xffffu ? 0u : tile[o0 + pxi * patch];
+            const unsigned hi = o1 == 0xffffu ? 0u : tile[o1 + pxi * patch];
+            w[j] = lo | (hi << 16);
+        }
+        *reinterpret_cast<u32x4*>(orow + (size_t)pxi * kpad + ch * 8) = u32x4{w[0], w[1], w[2], w[3]};
     }
 }
 
@@ -146,17 +166,20 @@ extern "C" int slime_im2col(const void* pixels, int pix_dtype, void* out, int n,
     SLIME_REQUIRE(pixels && out && n > 0, "im2col: bad input");
     SLIME_REQUIRE(image % patch == 0 && kpad % 8 == 0 && kpad >= 3 * patch * patch, "im2col: bad geometry");
     SLIME_REQUIRE(pix_dtype == SLIME_F32 || pix_dtype == dtype, "im2col: 16-bit pixels must already be in the tower dtype");
+    SLIME_REQUIRE(image % 8 == 0 && ((uintptr_t)pixels % 16) == 0, "im2col: image width must be a multiple of 8 and pixels 16-byte aligned");
+    SLIME_REQUIRE((size_t)3 * patch * image < 65535, "im2col: tile too large for the 16-bit offset table");
     const int g = image / patch;
-    const long total = (long)n * g * g * (kpad / 8);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t lds = ((size_t)3 * patch * image + kpad) * 2;
+    SLIME_REQUIRE(lds <= 64 * 1024, "im2col: %zu bytes of LDS needed", lds);
     hipStream_t s = (hipStream_t)stream;
     unsigned short* o = (unsigned short*)out;
+    const dim3 grid(n * g), block(256);
     if (dtype == SLIME_F16) {
-        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<F16, float>), dim3(blocks), dim3(256), 0, s, (const float*)pixels, o, n, image, patch, kpad);
-        else hipLaunchKernelGGL((im2col_kernel<F16, unsigned short>), dim3(blocks), dim3(256), 0, s, (const unsigned short*)pixels, o, n, image, patch, kpad);
+        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<F16, float>), grid, block, lds, s, (const float*)pixels, o, image, patch, kpad);
+        else hipLaunchKernelGGL((im2col_kernel<F16, unsigned short>), grid, block, lds, s, (const unsigned short*)pixels, o, image, patch, kpad);
     } else {
-        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<BF16, float>), dim3(blocks), dim3(256), 0, s, (const float*)pixels, o, n, image, patch, kpad);
-        else hipLaunchKernelGGL((im2col_kernel<BF16, unsigned short>), dim3(blocks), dim3(256), 0, s, (const unsigned short*)pixels, o, n, image, patch, kpad);
+        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<BF16, float>), grid, block, lds, s, (const float*)pixels, o, image, patch, kpad);
+        else hipLaunchKernelGGL((im2col_kernel<BF16, unsigned short>), grid, block, lds, s, (const unsigned short*)pixels, o, image, patch, kpad);
     }
     SLIME_CHECK_LAUNCH("im2col");
     return SLIME_OK;
