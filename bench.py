@@ -142,6 +142,11 @@ def main():
     # SLIME_BENCH_FORCE_COLLECTIVE=1: take the N>1 code path (RCCL init, all-gather, barrier, max-reduce) with a
     # single rank -- a self-test of that path on a 1-GPU box; the timed step then includes the 1-rank all-gather.
     collective = world > 1 or os.environ.get("SLIME_BENCH_FORCE_COLLECTIVE") == "1"
+    # stdout carries exactly one line (the JSON): libraries that write banners to fd 1 (RCCL prints its version / library path
+    # when a communicator is created) are sent to stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -259,7 +264,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
+        os.dup2(2, 1)
     if collective:
         dist.barrier()
         dist.destroy_process_group()
