@@ -150,8 +150,9 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                 for (int j = 0; j < 4; ++j) {
                     float a = acc[i][2 * p][j] + bias[p][j], b = acc[i][2 * p + 1][j] + bias[p][4 + j];
                     if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {          // x*sigmoid(1.702x)
-                        a = a * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * a));
-                        b = b * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * b));
+                        constexpr float C = -1.702f * 1.4426950408889634f;             // e^(-1.702 x) = 2^(C x): one multiply, then v_exp
+                        a = a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(C * a));
+                        b = b * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(C * b));
                     } else if constexpr (EPI == SLIME_EPI_BIAS_GELU_T) {        // erf GELU (nn.GELU())
                         a = gelu_erf(a);
                         b = gelu_erf(b);
