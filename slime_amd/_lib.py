@@ -101,6 +101,7 @@ _SIGNATURES = {
     "slime_gemm_set_sched": (None, [c_int]),
     "slime_gemm_set_ablation": (None, [c_int]),
     "slime_gemm_set_group_m": (None, [c_int]),
+    "slime_vit_set_skip_mask": (None, [c_int]),
     "slime_gemm_set_shape_tile": (None, [c_int, c_int, c_int]),
     "slime_gemm_set_debug": (None, [c_void_p]),
     "slime_attention_set_debug": (None, [c_void_p]),

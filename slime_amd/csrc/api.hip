@@ -78,11 +78,16 @@ extern "C" int slime_vit_forward(const slime_vit_desc* d, const void* pixels, in
     return slime_vit_forward_ex(d, pixels, pix_dtype, n, out, out_dtype, keep_cls, hidden_f32, ws, ws_bytes, stream, nullptr);
 }
 
+// diagnostic (results become wrong): bit k set = the tower skips kernel id k of every layer, to read each kernel's
+// MARGINAL cost inside the two-stream tower (tools/marginal_bench.py)
+static int g_vit_skip_mask = 0;
+extern "C" void slime_vit_set_skip_mask(int m) { g_vit_skip_mask = m; }
+
 #define PROBED(kid, call)                                                                             \
     do {                                                                                              \
         const bool on_ = probe && probe->layer == l && probe->kernel == (kid);                        \
         if (on_ && probe->start) (void)hipEventRecord((hipEvent_t)probe->start, (hipStream_t)stream);       \
-        TRY(call);                                                                                    \
+        if (!((g_vit_skip_mask >> (kid)) & 1)) TRY(call);                                             \
         if (on_ && probe->stop) (void)hipEventRecord((hipEvent_t)probe->stop, (hipStream_t)stream);          \
     } while (0)
 
