@@ -1366,6 +1366,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             // ... and multi-round grids run the four-wave stream kernel (same-box A/B inside the two-stream tower: fc1 and
             // qkv on the stream kernel 16.45 -> 15.72 ms; out_proj / fc2 on it lose 0.1-0.3 ms, they stay ping-pong)
             if (n256 >= 256) tile = c192 < c256 ? 10 : 11;
+            // ... and grids that would leave more than half of the CUs without a 256-row workgroup (single images, the adapter's
+            // 4608-row projections) take the 128x128 tile: 4x the workgroups, two per CU (M = 4608, N = K = 1024: 29 -> 16.5 us)
+            else if (n256 < 128) tile = 3;
         }
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
