@@ -131,7 +131,7 @@ class HipCLIPVisionModel(nn.Module):
         """[N,3,S,S] -> hidden_states[select_layer] as [N, P(+1), D] (one batched launch sequence)."""
         out_dtype = out_dtype or pixel_values.dtype
         n = pixel_values.shape[0]
-        if not (self.two_streams and n >= 8):
+        if not (self.two_streams and n >= 16):             # measured break-even: 14-16 crops (tools/small_streams.py)
             return ops.tower_forward(self.packed(select_layer), pixel_values, out_dtype, keep_cls)
         # two independent half batches on two streams: fills each kernel's last partial round
         if self._streams is None:
