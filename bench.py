@@ -137,6 +137,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     import torch.distributed as dist
+    # dry-run knobs for 1-GPU boxes (not used by the driver): SLIME_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # SLIME_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device) -- the numbers mean nothing then, the
+    # point is to execute the multi-process code path (rendezvous, gather, barrier, max-reduce, rank-0 print) for real
+    if os.environ.get("SLIME_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("SLIME_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SLIME_BENCH_FORCE_COLLECTIVE=1: take the N>1 code path (RCCL init, all-gather, barrier, max-reduce) with a
@@ -151,7 +157,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     from slime_amd import weights as W, ops
     from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
