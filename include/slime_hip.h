@@ -12,8 +12,10 @@
  *   - return 0 on success, a negative SLIME_E* code otherwise; never throws; slime_last_error()
  *     returns a thread-local message for the last failure;
  *   - no hidden allocation: scratch comes from the caller (`ws`, sized by the matching
- *     *_workspace_bytes query, 256-byte aligned); no global mutable state; calls on distinct
- *     streams with distinct workspaces may run concurrently;
+ *     *_workspace_bytes query, 256-byte aligned); no global mutable state (libslime_hip.so exports exactly the
+ *     functions declared here; the process-global tuning / ablation hooks used by tools/ live in a separate
+ *     diagnostic build, libslime_hip_diag.so, compiled from the same sources with -DSLIME_DIAG); calls on
+ *     distinct streams with distinct workspaces may run concurrently;
  *   - "T" is the 16-bit MFMA operand type selected by `dtype` (SLIME_BF16 or SLIME_F16); all
  *     accumulation, residual stream, LayerNorm and softmax statistics are fp32.
  */
@@ -27,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 1
+#define SLIME_ABI_VERSION 2
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 

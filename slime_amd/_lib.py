@@ -1,8 +1,13 @@
 """ctypes binding of ``libslime_hip.so`` (C ABI declared in ``include/slime_hip.h``).
 
 There is deliberately NO fallback: if the HIP library is missing or does not export the ABI the
-import of a compute entry point raises.  (``tests/test_abi.py`` checks, without a GPU, that every
-symbol the header declares is exported.)
+import of a compute entry point raises.  (``tests/test_host_logic.py::test_library_exports_exactly_the_header``
+checks, without a GPU, that the product library exports every symbol the header declares and nothing else.)
+
+Two builds of the same sources exist (slime_amd/csrc/Makefile):
+  * ``libslime_hip.so``       the product: the header's entry points, no mutable process state;
+  * ``libslime_hip_diag.so``  ``-DSLIME_DIAG``: adds process-global tuning / ablation hooks and the measured-alternative GEMM
+                              kernels.  Only ``tools/`` and the tile-forcing tests load it (``load_diag()`` / ``diag()``).
 """
 from __future__ import annotations
 
@@ -13,9 +18,11 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslime_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 2
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = range(5)
 
@@ -96,7 +103,10 @@ _SIGNATURES = {
     "slime_adapter_workspace_bytes": (c_size_t, [_P(MlpDesc), _P(ResamplerDesc), _P(ResamplerDesc), c_int, c_int]),
     "slime_adapter_forward": (c_int, [_P(MlpDesc), _P(ResamplerDesc), c_void_p, c_int, _P(ResamplerDesc), c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_size_t, c_void_p]),
-    # tuning hooks (not part of the reference-facing ABI)
+}
+
+# diagnostic build only (libslime_hip_diag.so): process-global hooks, never exported by the product library
+_DIAG_SIGNATURES = {
     "slime_gemm_force_tile": (None, [c_int]),
     "slime_gemm_set_sched": (None, [c_int]),
     "slime_gemm_set_ablation": (None, [c_int]),
@@ -110,6 +120,8 @@ _SIGNATURES = {
 }
 
 _lib = None
+_product = None
+_diag = None
 
 
 class SlimeHipError(RuntimeError):
@@ -134,24 +146,54 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def _bind(path: str, signatures) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    got = lib.slime_abi_version()
+    if got != ABI_VERSION:
+        raise SlimeHipError(f"{os.path.basename(path)} ABI version {got}, expected {ABI_VERSION}")
+    return lib
+
+
 def load():
-    """Load the library and bind prototypes; raises if it is missing (no CPU fallback exists)."""
-    global _lib
+    """The library every wrapper calls: the product library, unless a diagnostic session swapped in
+    ``libslime_hip_diag.so`` (``load_diag()`` / ``diag()``).  Raises if it is missing (no CPU fallback exists)."""
+    global _lib, _product
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SlimeHipError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C slime_amd/csrc`.  slime_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype, fn.argtypes = res, args
-    got = lib.slime_abi_version()
-    if got != 1:
-        raise SlimeHipError(f"libslime_hip ABI version {got}, expected 1")
-    _lib = lib
-    return lib
+    _product = _bind(LIB_PATH, _SIGNATURES)
+    _lib = _product
+    return _lib
+
+
+def load_diag():
+    """Switch this process to the diagnostic build (tools/): same ABI plus the ``slime_*_set_*`` / ``force_tile`` hooks."""
+    global _lib, _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise SlimeHipError(f"{DIAG_LIB_PATH} not found: `make -C slime_amd/csrc` builds it next to the product library")
+        _diag = _bind(DIAG_LIB_PATH, {**_SIGNATURES, **_DIAG_SIGNATURES})
+    _lib = _diag
+    return _lib
+
+
+class diag:
+    """``with _lib.diag() as lib:`` -- run the enclosed calls on the diagnostic build, then switch back to the product."""
+
+    def __enter__(self):
+        load()
+        return load_diag()
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = _product
+        return False
 
 
 def check(rc: int, what: str = "") -> None:

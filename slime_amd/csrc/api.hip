@@ -1,6 +1,7 @@
 // api.hip -- C-ABI drivers of libslime_hip: the CLIP tower layer loop, the Resampler, the projector
 // MLP and the GatedBlock, each a fixed sequence of the primitive kernels on one stream.  No
-// allocation, no synchronisation, no global mutable state: callable under hipGraph capture.
+// allocation, no synchronisation, no global mutable state (the last-error string is thread-local): callable under
+// hipGraph capture.
 #include <stdarg.h>
 #include <string.h>
 #include "common.h"
@@ -78,10 +79,14 @@ extern "C" int slime_vit_forward(const slime_vit_desc* d, const void* pixels, in
     return slime_vit_forward_ex(d, pixels, pix_dtype, n, out, out_dtype, keep_cls, hidden_f32, ws, ws_bytes, stream, nullptr);
 }
 
-// diagnostic (results become wrong): bit k set = the tower skips kernel id k of every layer, to read each kernel's
+// diagnostic build only (libslime_hip_diag.so; results become wrong): bit k set = the tower skips kernel id k of every layer, to read each kernel's
 // MARGINAL cost inside the two-stream tower (tools/marginal_bench.py)
+#ifdef SLIME_DIAG
 static int g_vit_skip_mask = 0;
 extern "C" void slime_vit_set_skip_mask(int m) { g_vit_skip_mask = m; }
+#else
+static constexpr int g_vit_skip_mask = 0;
+#endif
 
 #define PROBED(kid, call)                                                                             \
     do {                                                                                              \

@@ -278,12 +278,7 @@ static int launch_attn(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
     constexpr int LDS = 2 * KC * DH * 2;
     auto kern = attn_kernel<T, DH, KC, NW, NSUBMAX>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
     const int cap = NW * NSUBMAX;
     const int qsplit = (total_sb + cap - 1) / cap;
@@ -593,12 +588,7 @@ static int launch_attn64(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
     constexpr int LDS = 2 * 608 * 128;
     auto kern = attn64_kernel<T>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
     const int qsplit = (total_sb + 23) / 24;                  // <= 3 sub-blocks per wave, 8 waves
     a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
@@ -607,12 +597,17 @@ static int launch_attn64(const AttnArgs& a0, int batch, hipStream_t stream) {
     return SLIME_OK;
 }
 
+#ifdef SLIME_DIAG   // diagnostic build only (libslime_hip_diag.so): the product library has no mutable globals
 static unsigned long long* g_attn_dbg = nullptr;
 static int g_attn_abl = 0;
 extern "C" void slime_attention_set_ablation(int v) { g_attn_abl = v; }
-static int g_attn_variant = 0;      // test/bench hook: 1 = force the generic kernel
+static int g_attn_variant = 0;      // 1 = force the generic kernel
 extern "C" void slime_attention_set_variant(int v) { g_attn_variant = v; }
 extern "C" void slime_attention_set_debug(void* p) { g_attn_dbg = (unsigned long long*)p; }
+#else
+static constexpr unsigned long long* g_attn_dbg = nullptr;
+static constexpr int g_attn_abl = 0, g_attn_variant = 0;
+#endif
 
 extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs,
                                const void* v, long v_bs, long v_rs, void* o, long o_bs, long o_rs,

@@ -98,4 +98,13 @@ void slime_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+// One-time opt-in of a kernel to > 64 KiB of dynamic LDS.  A function-local static is initialised exactly once, thread-safely
+// (C++11), per kernel instantiation; one process drives one GPU, so once per process is once per device.
+#define SLIME_SET_LDS_ONCE(kern, lds, what)                                                                            \
+    do {                                                                                                               \
+        static const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                          \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (lds));           \
+        if (e_ != hipSuccess) { slime_set_error(what ": hipFuncSetAttribute: %s", hipGetErrorString(e_)); return SLIME_ELAUNCH; } \
+    } while (0)
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -69,6 +69,16 @@ __device__ __forceinline__ unsigned lds_byte_addr(const char* p) {
     return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }
 
+// CU count of the current device (queried once; immutable afterwards): grid-quantisation rules count rounds of this many workgroups
+static int num_cus() {
+    static const int n = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
+
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
@@ -739,6 +749,7 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 }
 
 
+#ifdef SLIME_DIAG   // measured alternatives: compiled into libslime_hip_diag.so only
 // ================================================================================================
 // Persistent ping-pong kernel: the ping-pong kernel above, but a workgroup walks its output tiles
 // (tile = blockIdx.x, + gridDim.x, ...) as ONE continuous k-tile stream.
@@ -923,22 +934,12 @@ __global__ void __launch_bounds__(512) gemm_ppp_kernel(GemmArgs g) {
     }
 }
 
-static int g_num_cu = 0;
 template <typename T, int EPI, int KTAG>
 static int launch_ppp_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int LDS = 2 * (256 + 256) * 64 * 2;
     auto kern = gemm_ppp_kernel<T, EPI, KTAG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("gemm_ppp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
-    if (g_num_cu == 0) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { slime_set_error("gemm_ppp: device query failed"); return SLIME_ELAUNCH; }
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "gemm_ppp");
+    const int g_num_cu = num_cus();
     const int ntiles = ((g.M + 255) / 256) * (g.N / 256);
     int grid = ntiles < g_num_cu ? ntiles : (g_num_cu / 8) * 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, g);
@@ -1219,12 +1220,7 @@ template <typename T, int EPI, int KTAG>
 static int launch_pp32b_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int LDS = 2 * (256 + 256) * 64 * 2;
     auto kern = gemm_pp32b_kernel<T, EPI, KTAG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("gemm_pp32b: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "gemm_pp32b");
     const int tiles_m = (g.M + 255) / 256, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_pp32b");
@@ -1235,24 +1231,28 @@ static int launch_pp32b(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp32b_k<T, EPI, 1>(g, stream) : launch_pp32b_k<T, EPI, 0>(g, stream);
 }
 
+#endif  // SLIME_DIAG (persistent / 32x32x16 variants)
+
+// Process-global tuning / ablation hooks exist in the DIAGNOSTIC build only (libslime_hip_diag.so, -DSLIME_DIAG: tools/ and
+// the tile-forcing tests).  The product library has no mutable global state: dispatch is a pure function of the shape.
+#ifdef SLIME_DIAG
 static int g_ablation = 0;
 static int g_group_m = 0;
 static unsigned long long* g_dbg = nullptr;
 extern "C" void slime_gemm_set_debug(void* p) { g_dbg = (unsigned long long*)p; }
 extern "C" void slime_gemm_set_ablation(int a) { g_ablation = a; }
 extern "C" void slime_gemm_set_group_m(int s) { g_group_m = s; }
+#else
+static constexpr int g_group_m = 0;
+static constexpr unsigned long long* g_dbg = nullptr;
+#endif
 
 template <typename T, int EPI, int KTAG, int ABL, int MT = 4>
 static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 64 * MT;
     constexpr int LDS = 2 * (BM + 256) * 64 * 2;
     auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL, MT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("gemm_pp: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "gemm_pp");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_pp");
@@ -1261,6 +1261,7 @@ static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
 
 template <typename T, int EPI>
 static int launch_pp(const GemmArgs& g, hipStream_t stream) {
+#ifdef SLIME_DIAG
     if constexpr (EPI == SLIME_EPI_BIAS_T && T::id == SLIME_BF16) {     // ablation builds: one epilogue only
         switch (g_ablation) {
             case 1: return launch_pp_k<T, EPI, 0, 1>(g, stream);
@@ -1272,6 +1273,7 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
             default: break;
         }
     }
+#endif
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0>(g, stream) : launch_pp_k<T, EPI, 0, 0>(g, stream);
 }
 
@@ -1280,12 +1282,7 @@ static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MI;
     constexpr int LDS = 2 * (BM + 256) * 64 * 2 + 64;               // + the split-barrier counter
     auto kern = gemm_w4_kernel<T, EPI, KTAG, MI, ABL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("gemm_w4: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "gemm_w4");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_w4");
@@ -1294,6 +1291,7 @@ static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
 
 template <typename T, int EPI, int MI>
 static int launch_w4(const GemmArgs& g, hipStream_t stream) {
+#ifdef SLIME_DIAG
     if constexpr (EPI == SLIME_EPI_BIAS_T && T::id == SLIME_BF16 && MI == 8) {     // ablation builds: one configuration only
         switch (g_ablation) {
             case 1: return launch_w4_k<T, EPI, 0, MI, 1>(g, stream);
@@ -1305,6 +1303,7 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
             default: break;
         }
     }
+#endif
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 
@@ -1318,28 +1317,47 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * 64 * 2;
     constexpr int LDS = 2 * STAGE;
     auto kern = gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, EPI, SCHED>;
-    static bool attr_set = false;   // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) { slime_set_error("gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return SLIME_ELAUNCH; }
-        attr_set = true;
-    }
+    SLIME_SET_LDS_ONCE(kern, LDS, "gemm");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(WAVES_M * WAVES_N * 64), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm");
     return SLIME_OK;
 }
 
-// Tile choice.  The 256x256 ping-pong kernel is the throughput kernel (measured equal or better than
-// the lock-step 256x256 / 256x128 variants inside the tower); 128x128 (4 waves, 64 KiB LDS, 2 WG/CU)
-// covers narrow N (tiny geometries) and small M.  Partial last rounds of workgroups are filled by
-// running two half batches on two streams (see HipCLIPVisionModel.encode), not by shrinking the tile.
-static int g_force_tile = 0;   // test/bench hook: 0 auto, 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 = 192x256 / 256x256 four-wave stream kernel (auto: 4 for sub-round grids, else 10 or 11), 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong
-static int g_sched = 1;        // test/bench hook: 0 = compiler schedule, 1 = pinned software pipeline
+// Tile choice (a pure function of the shape and of the device's CU count).  The 256-row stream / ping-pong kernels are the
+// throughput kernels; 128x128 (4 waves, 64 KiB LDS, 2 WG/CU) covers narrow N (tiny geometries) and small M.  Partial last
+// rounds of workgroups are filled by running two half batches on two streams (see HipCLIPVisionModel.encode), not by
+// shrinking the tile.  Tile ids: 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 =
+// 192x256 / 256x256 four-wave stream kernel; diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
+static int auto_tile(const GemmArgs& g) {
+    int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
+    if (tile == 4) {
+        // Row-tile height by grid quantisation, for grids of at least one full round of CUs: rounds x per-
+        // workgroup time (~ rows + a fixed share).  qkv at 11540 rows: 552 tiles of 256 rows = 3 rounds, 732 tiles
+        // of 192 rows = 3 rounds of 3/4-size workgroups (772 -> 866 TF/s).  Sub-round grids (out_proj / fc2: 184
+        // tiles) would gain even more stand-alone (994 -> 1216 TF/s) but LOSE 2.5 % inside the two-stream tower,
+        // where the idle CUs of a 0.72-round launch are taken by the other stream's kernels: they keep 256 rows.
+        const long cus = num_cus();
+        const long tn = g.N / 256;
+        const long n256 = ((g.M + 255) / 256) * tn, n192 = ((g.M + 191) / 192) * tn;
+        const long c256 = (n256 + cus - 1) / cus * (256 + 40);
+        const long c192 = (n192 + cus - 1) / cus * (192 + 40);
+        // ... and multi-round grids run the four-wave stream kernel (same-box A/B inside the two-stream tower: fc1 and
+        // qkv on the stream kernel 16.45 -> 15.72 ms; out_proj / fc2 on it lose 0.1-0.3 ms, they stay ping-pong)
+        if (n256 >= cus) tile = c192 < c256 ? 10 : 11;
+        // ... and grids that would leave more than half of the CUs without a 256-row workgroup (single images, the adapter's
+        // 4608-row projections) take the 128x128 tile: 4x the workgroups, two per CU (M = 4608, N = K = 1024: 29 -> 16.5 us)
+        else if (n256 < cus / 2) tile = 3;
+    }
+    return tile;
+}
+
+#ifdef SLIME_DIAG
+static int g_force_tile = 0;   // 0 = auto_tile()
+static int g_sched = 1;        // 0 = compiler schedule, 1 = pinned software pipeline (lock-step kernels)
 extern "C" void slime_gemm_force_tile(int t) { g_force_tile = t; }
 extern "C" void slime_gemm_set_sched(int s) { g_sched = s; }
-// bench hook: per-shape tile override table (N, K) -> tile, consulted in auto mode; tile 0 clears the table
+// per-shape tile override table (N, K) -> tile, consulted in auto mode; tile 0 clears the table
 static int g_rule_n[8], g_rule_k[8], g_rule_tile[8], g_rules = 0;
 extern "C" void slime_gemm_set_shape_tile(int N, int K, int tile) {
     if (tile == 0) { g_rules = 0; return; }
@@ -1347,32 +1365,16 @@ extern "C" void slime_gemm_set_shape_tile(int N, int K, int tile) {
         if (g_rule_n[i] == N && g_rule_k[i] == K) { g_rule_tile[i] = tile; return; }
     if (g_rules < 8) { g_rule_n[g_rules] = N; g_rule_k[g_rules] = K; g_rule_tile[g_rules] = tile; ++g_rules; }
 }
+#endif
 
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
-    int tile = g_force_tile;
-    if (tile == 0) {
-        tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
-        if (tile == 4) {
-            // Row-tile height by grid quantisation, for grids of at least one full round of 256 CUs: rounds x per-
-            // workgroup time (~ rows + a fixed share).  qkv at 11540 rows: 552 tiles of 256 rows = 3 rounds, 732 tiles
-            // of 192 rows = 3 rounds of 3/4-size workgroups (772 -> 866 TF/s).  Sub-round grids (out_proj / fc2: 184
-            // tiles) would gain even more stand-alone (994 -> 1216 TF/s) but LOSE 2.5 % inside the two-stream tower,
-            // where the idle CUs of a 0.72-round launch are taken by the other stream's kernels: they keep 256 rows.
-            const long tn = g.N / 256;
-            const long n256 = ((g.M + 255) / 256) * tn, n192 = ((g.M + 191) / 192) * tn;
-            const long c256 = (n256 + 255) / 256 * (256 + 40);
-            const long c192 = (n192 + 255) / 256 * (192 + 40);
-            // ... and multi-round grids run the four-wave stream kernel (same-box A/B inside the two-stream tower: fc1 and
-            // qkv on the stream kernel 16.45 -> 15.72 ms; out_proj / fc2 on it lose 0.1-0.3 ms, they stay ping-pong)
-            if (n256 >= 256) tile = c192 < c256 ? 10 : 11;
-            // ... and grids that would leave more than half of the CUs without a 256-row workgroup (single images, the adapter's
-            // 4608-row projections) take the 128x128 tile: 4x the workgroups, two per CU (M = 4608, N = K = 1024: 29 -> 16.5 us)
-            else if (n256 < 128) tile = 3;
-        }
+    int tile = auto_tile(g);
+#ifdef SLIME_DIAG
+    if (g_force_tile != 0) tile = g_force_tile;
+    else
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
-    }
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
     if (tile == 6 || tile == 8) tile = 7;
@@ -1380,20 +1382,14 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
     if (tile == 5) return launch_ppp<T, EPI>(g, stream);
-    if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 9) return launch_pp192<T, EPI>(g, stream);
+    if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
+    if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
+#endif
+    if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
     if (tile == 11) return launch_w4<T, EPI, 8>(g, stream);
-    if (g_sched == 0) {
-        switch (tile) {
-            case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream);
-            default: return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
-        }
-    }
-    switch (tile) {
-        case 1: return launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
-        default: return launch_cfg<T, 128, 128, 2, 2, EPI, 1>(g, stream);
-    }
+    return launch_cfg<T, 128, 128, 2, 2, EPI, 1>(g, stream);
 }
 
 template <typename T>

@@ -39,32 +39,49 @@ def _rand(shape, dtype, dev, seed, scale=1.0):
 @pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (3, 1), (3, 0), (0, 1), (4, 1), (5, 1), (7, 1), (9, 1), (10, 1), (11, 1)])
 @pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128)])
 def test_gemm_epilogues(dev, dtype, tile, sched, M, N, K):
+    """Every tile / kernel variant (forced through the DIAGNOSTIC build's hook) x every epilogue vs fp32 torch."""
+    from slime_amd import _lib
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(tile)
+        lib.slime_gemm_set_sched(sched)
+        try:
+            _check_all_epilogues(dev, dtype, M, N, K)
+        finally:
+            lib.slime_gemm_force_tile(0)
+            lib.slime_gemm_set_sched(1)
+
+
+def _check_all_epilogues(dev, dtype, M, N, K):
     from slime_amd import ops, _lib
-    lib = _lib.load()
     a = _rand((M, K), dtype, dev, 1)
     w = _rand((N, K), dtype, dev, 2, K ** -0.5)     # asymmetric, random: catches row/col swaps
     bias = _rand((N,), torch.float32, dev, 3)
     ref = a.float() @ w.float().t() + bias
-    lib.slime_gemm_force_tile(tile)
-    lib.slime_gemm_set_sched(sched)
-    try:
-        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_F32)
-        assert rel_l2(out.cpu(), ref.cpu()) < TOL_F32
-        out = ops.gemm(a, w, None, _lib.EPI_BIAS_F32)
-        assert rel_l2(out.cpu(), (ref - bias).cpu()) < TOL_F32
-        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_T)
-        assert out.dtype == dtype and rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype]
-        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_QUICKGELU_T)
-        assert rel_l2(out.float().cpu(), (ref * torch.sigmoid(1.702 * ref)).cpu()) < TOL_T[dtype]
-        out = ops.gemm(a, w, bias, _lib.EPI_BIAS_GELU_T)
-        assert rel_l2(out.float().cpu(), F.gelu(ref).cpu()) < TOL_T[dtype]
-        h = _rand((M, N), torch.float32, dev, 4)
-        h0 = h.clone()
-        ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h)
-        assert rel_l2(h.cpu(), (h0 + ref).cpu()) < TOL_F32
-    finally:
-        lib.slime_gemm_force_tile(0)
-        lib.slime_gemm_set_sched(1)
+    out = ops.gemm(a, w, bias, _lib.EPI_BIAS_F32)
+    assert rel_l2(out, ref) < TOL_F32
+    out = ops.gemm(a, w, None, _lib.EPI_BIAS_F32)
+    assert rel_l2(out, ref - bias) < TOL_F32
+    out = ops.gemm(a, w, bias, _lib.EPI_BIAS_T)
+    assert out.dtype == dtype and rel_l2(out.float(), ref) < TOL_T[dtype]
+    out = ops.gemm(a, w, bias, _lib.EPI_BIAS_QUICKGELU_T)
+    assert rel_l2(out.float(), ref * torch.sigmoid(1.702 * ref)) < TOL_T[dtype]
+    out = ops.gemm(a, w, bias, _lib.EPI_BIAS_GELU_T)
+    assert rel_l2(out.float(), F.gelu(ref)) < TOL_T[dtype]
+    h = _rand((M, N), torch.float32, dev, 4)
+    h0 = h.clone()
+    ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h)
+    assert rel_l2(h, h0 + ref) < TOL_F32
+
+
+# The tower's production launch shapes (20-crop half batch M = 11540; the stacked adapter MLP M = 13824), AUTO dispatch of the
+# PRODUCT library, every epilogue, against fp32 torch on the same rounded operands.  K >= 2048 reaches the KTAG = 1
+# instantiations: gemm_pp_kernel<T, EPI, 1, 0, 4> (fc2 + residual: N = 1024, K = 4096, sub-round grid -> ping-pong) and
+# gemm_w4_kernel<T, EPI, 1, MI> (N = 4096: multi-round grid -> four-wave stream kernel, hand-fenced epilogue).
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(11540, 1024, 4096), (11540, 4096, 1024), (11540, 3072, 1024), (11540, 1024, 1024),
+                                   (13824, 4096, 4096), (13824, 4096, 1024), (11540, 1024, 2048), (23080, 4096, 2048)])
+def test_gemm_production_shapes(dev, dtype, M, N, K):
+    _check_all_epilogues(dev, dtype, M, N, K)
 
 
 def test_gemm_strided_and_identity(dev):

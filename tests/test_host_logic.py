@@ -13,14 +13,27 @@ from conftest import GOLDEN
 PIN = "[(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]"
 
 
-def test_abi_exports_every_header_symbol():
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
+def test_library_exports_exactly_the_header():
+    """The product library exports every function include/slime_hip.h declares and NOTHING else (no diagnostic hooks, no
+    kernel stubs); the hooks live in the separate -DSLIME_DIAG build."""
     from slime_amd import _lib
     lib = _lib.load()
-    syms = _lib.header_symbols()
-    assert len(syms) >= 20
+    syms = set(_lib.header_symbols())
+    assert len(syms) >= 30
     for s in syms:
         assert hasattr(lib, s), f"libslime_hip.so does not export {s}"
-    assert lib.slime_abi_version() == 1
+    assert lib.slime_abi_version() == _lib.ABI_VERSION == 2
+    assert _exported(_lib.LIB_PATH) == syms
+    assert set(_lib._SIGNATURES) == syms, "slime_amd/_lib.py binds exactly the header's functions"
+    if os.path.exists(_lib.DIAG_LIB_PATH):
+        extra = _exported(_lib.DIAG_LIB_PATH) - syms
+        assert extra == set(_lib._DIAG_SIGNATURES), extra
 
 
 def test_grid_tables_match_reference():

@@ -2,7 +2,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 B = 16
 qkv = torch.randn(B, 577, 3072, device=dev).to(dt); qkv[..., :1024] *= 0.125
 q, k, v = qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:]

@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 lib.slime_gemm_force_tile(4)
 for M, N, K, reps in ((16384, 1024, 4096, 1), (16384, 1024, 4096, 20), (16384, 1024, 16384, 10), (16384, 1024, 1024, 20), (32768, 1024, 1024, 20), (16384 * 4, 1024, 1024, 20)):
     a = torch.randn(M, K, device=dev).to(dt); w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)

@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 for (M, N, K) in ((256, 256, 64), (256, 256, 128)):
     a = torch.ones(M, K, device=dev).to(dt); w = torch.ones(N, K, device=dev).to(dt); b = torch.zeros(N, device=dev)
     lib.slime_gemm_force_tile(11)

@@ -3,7 +3,7 @@
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib, weights as W
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 tsd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)
 px = W.synthetic_pixels(40, seed=0).to(dev).to(dt)
 pts = [ops.pack_tower(tsd, W.CLIP_L_336, dt, dev) for _ in range(2)]

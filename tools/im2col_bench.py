@@ -1,7 +1,7 @@
 import sys, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import _lib
-lib = _lib.load(); dev = torch.device("cuda:0")
+lib = _lib.load_diag(); dev = torch.device("cuda:0")
 n = 20
 px = torch.randn(n, 3, 336, 336, device=dev).to(torch.bfloat16)
 out = torch.empty((n * 576, 640), dtype=torch.bfloat16, device=dev)

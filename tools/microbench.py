@@ -26,7 +26,7 @@ def timeit(fn, warm=3, it=10):
 
 def main():
     dev = torch.device("cuda:0")
-    lib = _lib.load()
+    lib = _lib.load_diag()
     res = {}
     dt = torch.bfloat16
     n_crops = int(os.environ.get("CROPS", "40"))

@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 lib.slime_gemm_force_tile(4)
 def q(x): return f"mean {x.mean():8.0f} p10 {x.quantile(0.1):8.0f} p50 {x.median():8.0f} p90 {x.quantile(0.9):8.0f} max {x.max():8.0f}"
 for M, N, K in ((11540, 4096, 1024), (23080, 4096, 1024), (23080, 1024, 4096)):

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib, weights as W
 
 dev = torch.device("cuda:0")
-lib = _lib.load()
+lib = _lib.load_diag()
 dt = torch.bfloat16
 N = int(os.environ.get("CROPS", "40"))
 tsd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)

@@ -3,7 +3,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slime_amd import ops, _lib
-dev = torch.device("cuda:0"); lib = _lib.load(); dt = torch.bfloat16
+dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 def timeit(fn, warm=3, it=20):
     for _ in range(warm): fn()
     torch.cuda.synchronize()
