@@ -65,6 +65,30 @@ def _uniform_layout(split_sizes, image_sizes, cfg, crop: int, merge_type: str):
     return (n_local, nw, nh, True) if nw * nh == n_local else None
 
 
+def _project_local(projector, comp: torch.Tensor) -> torch.Tensor:
+    """``mm_projector`` on the compressed local crops [sum n_i, g*g, D] of a whole batch.  The reference calls the projector
+    per image (n_i <= 7 crops), where GatedBlock.forward's test ``x.shape[0] != 576 and x.shape[1] != 576``
+    (projector/builder.py:180-181) always takes the plain-MLP return; on the batch-stacked tensor dim 0 is sum n_i and may
+    equal 576 by accident, so the MLP is called directly instead of through that shape test."""
+    if isinstance(projector, GatedBlock):
+        return projector.projection(comp, out_dtype=torch.float32)
+    return projector(comp, out_dtype=torch.float32)
+
+
+def _require_inference(model) -> None:
+    """The HIP path has no backward.  The reference's pretrain / finetune stages train mm_projector and sampler through
+    this code (train.py:1100-1130); silently detaching them under @torch.no_grad would freeze the adapter without a
+    message, so training-mode use is an error here ("inference only")."""
+    if not torch.is_grad_enabled():
+        return
+    for name in ("mm_projector", "sampler"):
+        mod = getattr(model, name, None)
+        if mod is not None and any(p.requires_grad and p.is_floating_point() for p in mod.parameters()) and mod.training:
+            raise RuntimeError(
+                f"slime_amd is inference-only: {name} has trainable parameters and autograd is enabled, but the HIP adapter "
+                "has no backward.  Call .eval() / .requires_grad_(False), or run under torch.no_grad().")
+
+
 def _fused_adapter(model, images: torch.Tensor, layout, out_dtype: torch.dtype, out: Optional[torch.Tensor] = None):
     """tower -> slime_adapter_forward for a uniform batch: tokens [B, 576 + n*g*g, H]."""
     n_local, nw, nh, merge = layout
@@ -129,9 +153,13 @@ class SlimeMetaForCausalLM(ABC):
         return embs, masks
 
     # ------------------------------------------------------------------ the hot path
-    @torch.no_grad()
     def encode_images(self, images, input_ids=None, split_sizes=None, attention_mask=None, images_mask=None,
                       image_sizes=None, labels=None):
+        _require_inference(self.get_model())
+        with torch.no_grad():
+            return self._encode_images(images, input_ids, split_sizes, attention_mask, images_mask, image_sizes, labels)
+
+    def _encode_images(self, images, input_ids, split_sizes, attention_mask, images_mask, image_sizes, labels):
         model = self.get_model()
         tower = model.get_vision_tower()
         cfg = self.config
@@ -165,7 +193,7 @@ class SlimeMetaForCausalLM(ABC):
                 glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)             # [B,576,H]
             if not use_global_only:
                 comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)    # [sum n_i,144,D]
-                loc = model.mm_projector(comp, out_dtype=torch.float32)                          # [sum n_i,144,H]
+                loc = _project_local(model.mm_projector, comp)                                   # [sum n_i,144,H]
             g = model.sampler.grid_size
             outs = []
             lstart = 0
@@ -249,6 +277,7 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         super().__init__()
         self.config = config
         self.model = _VisualModel(config, embed_tokens)
+        self.eval()                     # inference front end (a from_pretrained HF model arrives in eval mode as well)
 
     def get_model(self):
         return self.model
@@ -258,7 +287,8 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         if not vt.is_loaded:
             vt.load_model()
         if tower_sd is not None:
-            vt.vision_tower.load_state_dict(tower_sd, strict=False)
+            from .multimodal_encoder.clip_encoder import check_tower_keys
+            check_tower_keys(vt.vision_tower.load_state_dict(tower_sd, strict=False), "<state dict>")
         if adapter_sd is not None:
             from ..weights import sub_state
             self.model.mm_projector.load_state_dict(sub_state(adapter_sd, "mm_projector."), strict=True)
@@ -287,7 +317,7 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         if n_local == 0:
             return [(glob[i], glob.new_zeros((0, glob.shape[-1]))) for i in range(len(split_sizes))]
         comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)
-        loc = model.mm_projector(comp, out_dtype=torch.float32)
+        loc = _project_local(model.mm_projector, comp)
         g = model.sampler.grid_size
         outs, lstart = [], 0
         for i, s in enumerate(split_sizes):

@@ -195,6 +195,17 @@ def _resolve_local(name: str) -> str:
             f"Pass a directory with config.json + model.safetensors, or '{SYNTHETIC_PREFIX}<seed>'.") from e
 
 
+def check_tower_keys(result, source: str) -> None:
+    """The parameter container starts uninitialised, so a checkpoint with another naming scheme (open_clip, a partial
+    file) must not load silently: only the dead ``post_layernorm`` (never run: hidden_states[-2]) and HF's ``position_ids``
+    buffer may be absent, and nothing may be left over."""
+    missing = [k for k in result.missing_keys if "post_layernorm" not in k and "position_ids" not in k]
+    unexpected = [k for k in result.unexpected_keys if "position_ids" not in k]
+    if missing or unexpected:
+        raise RuntimeError(f"vision tower checkpoint {source!r} does not match the CLIP ViT layout: "
+                           f"{len(missing)} missing (e.g. {missing[:3]}), {len(unexpected)} unexpected (e.g. {unexpected[:3]})")
+
+
 class CLIPVisionTower(nn.Module):
     def __init__(self, vision_tower, args, delay_load=False):
         super().__init__()
@@ -231,7 +242,7 @@ class CLIPVisionTower(nn.Module):
         if cfg.hidden_act != "quick_gelu":
             raise ValueError(f"unsupported CLIP activation {cfg.hidden_act!r}: the HIP tower implements quick_gelu")
         self.vision_tower = HipCLIPVisionModel(cfg, self._compute_dtype)
-        self.vision_tower.load_state_dict(sd, strict=False)
+        check_tower_keys(self.vision_tower.load_state_dict(sd, strict=False), name)
         if device_map not in (None, "auto") and not isinstance(device_map, dict):
             self.vision_tower.to(device_map)
         self.vision_tower.requires_grad_(False)

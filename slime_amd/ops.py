@@ -252,6 +252,11 @@ def pack_resampler(sd: Dict[str, torch.Tensor], dim: int, heads: int, n_kv: int,
     E = dim
     in_w, in_b = sd["attn.in_proj_weight"].float().cpu(), sd["attn.in_proj_bias"].float().cpu()
     pos_q = sd["pos_embed"].cpu()
+    if torch.isnan(pos_q.float()).any():
+        # sampler.py:150-154 ("some init error"): a stored table that contains NaN is regenerated from the sincos
+        # formula in the stored dtype.  The reference tests this on the device at every call; here once, at pack time.
+        from .weights import sincos_pos_embed_2d
+        pos_q = torch.from_numpy(sincos_pos_embed_2d(dim, int(math.isqrt(nq)))).to(pos_q.dtype)
     q = F.layer_norm(sd["query"].float().cpu(), (E,), sd["ln_q.weight"].float().cpu(), sd["ln_q.bias"].float().cpu(), eps)
     q = F.linear(q + pos_q.float(), in_w[:E], in_b[:E]) * (dh ** -0.5 * LOG2E)
     pos_k = _abs_pos(pos_q, side).float()

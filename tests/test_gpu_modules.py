@@ -354,3 +354,19 @@ def test_cfg3_layout_17_crops_vs_oracle(dev, dtype):
         merged = O.spatial_merge(loc, nw, nh, 12)
         assert rel_l2(tokens[i, :576], glob) < TOL[dtype] * 1.5
         assert rel_l2(tokens[i, 576:], merged) < TOL[dtype] * 2
+
+
+def test_stacked_local_crops_of_576_take_the_mlp(dev):
+    """the ragged path projects the batch-stacked compressed local crops [sum n_i, 144, D] in one call; with
+    exactly 576 local crops in the batch GatedBlock.forward's shape test (dim0 == 576) must not be what decides -- the MLP
+    is called directly, like the reference's per-image calls always end up doing."""
+    from slime_amd.model.llava_arch import _project_local
+    enc, _, asd = _tiny_encoder(dev, torch.bfloat16)
+    proj = enc.get_model().mm_projector
+    comp = torch.randn(576, 144, 128, generator=torch.Generator().manual_seed(5)).to(dev)
+    out = _project_local(proj, comp)
+    assert out.shape == (576, 144, 256)
+    part = proj.projection(comp[:5], out_dtype=torch.float32)
+    assert torch.equal(out[:5], part)
+    with pytest.raises(ValueError, match="GatedBlock expects"):
+        proj(comp)                                             # the shape test itself is the reference's (builder.py:180)

@@ -155,3 +155,55 @@ def test_resample_tables_match_oracle(sizes):
     xmin, cnt, fixed = R.coefficients(*sizes)
     assert np.array_equal(bounds[:, 0], xmin) and np.array_equal(bounds[:, 1], cnt)
     assert np.array_equal(kk, fixed)
+
+
+def test_training_mode_is_rejected_not_silently_detached():
+    """the HIP adapter has no backward; training-mode use with trainable adapter parameters raises (before any
+    device work) instead of silently freezing the adapter; eval mode / no_grad / frozen parameters pass the guard."""
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config, _require_inference
+    enc = SlimeVisualEncoder(default_slime_config("synthetic:1", hidden_size=256, mm_hidden_size=128))
+    assert not enc.training
+    _require_inference(enc.get_model())                       # eval mode: fine
+    enc.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        enc.encode_images(torch.zeros(1, 3, 336, 336), input_ids=torch.zeros(1, 4, dtype=torch.long), split_sizes=[1])
+    with torch.no_grad():
+        _require_inference(enc.get_model())
+    enc.get_model().mm_projector.requires_grad_(False)
+    enc.get_model().sampler.requires_grad_(False)
+    _require_inference(enc.get_model())
+
+
+def test_tower_checkpoint_key_mismatch_raises():
+    """a checkpoint with another naming scheme / a partial one must not run on uninitialised weights."""
+    from slime_amd import weights as W
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel, check_tower_keys
+    m = HipCLIPVisionModel(W.TINY)
+    sd = W.make_tower_state_dict(W.TINY, seed=3)
+    ok = {k: v for k, v in sd.items() if "post_layernorm" not in k}
+    check_tower_keys(m.load_state_dict(ok, strict=False), "ok")                    # the dead post_layernorm may be absent
+    part = {k: v for k, v in sd.items() if "layers.1." not in k}
+    with pytest.raises(RuntimeError, match="missing"):
+        check_tower_keys(m.load_state_dict(part, strict=False), "partial")
+    renamed = {k.replace("self_attn.q_proj", "attn.in_proj_q"): v for k, v in sd.items()}     # open_clip-like names
+    with pytest.raises(RuntimeError, match="unexpected"):
+        check_tower_keys(m.load_state_dict(renamed, strict=False), "renamed")
+
+
+def test_resampler_pack_regenerates_nan_pos_embed():
+    """ADVICE r1 / sampler.py:150-154: a stored pos_embed with NaN is replaced by the sincos table at pack time."""
+    from slime_amd import ops, weights as W
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=12)
+    sd = dict(W.sub_state(asd, "sampler.post_qformer."))
+    good = ops.pack_resampler(sd, 128, 1, 576, torch.bfloat16, "cpu")
+    bad = dict(sd)
+    bad["pos_embed"] = sd["pos_embed"].clone()
+    bad["pos_embed"][3, 5] = float("nan")
+    fixed = ops.pack_resampler(bad, 128, 1, 576, torch.bfloat16, "cpu")
+    ref = dict(sd)
+    ref["pos_embed"] = torch.from_numpy(W.sincos_pos_embed_2d(128, 12)).to(sd["pos_embed"].dtype)
+    want = ops.pack_resampler(ref, 128, 1, 576, torch.bfloat16, "cpu")
+    for k in ("q_proj", "pos_k"):
+        assert torch.isfinite(fixed.tensors[k].float()).all()
+        assert torch.equal(fixed.tensors[k], want.tensors[k])
+    assert torch.isfinite(good.tensors["q_proj"].float()).all()
