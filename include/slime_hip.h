@@ -281,6 +281,50 @@ int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resampler_desc*
                           int n_images, int n_local, int nw, int nh, int merge, void* out, int out_dtype,
                           long out_image_stride, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * After the visual tokens: splice into the text embeddings, Llama prefill attention
+ * ---------------------------------------------------------------------------------------------- */
+
+/* new_input_embeds of prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:343-459), all rows of the padded
+ * batch in one launch: out[r, :] = table[src[r], :] if src[r] >= 0 (embed_tokens row of a text token),
+ * feats[-2 - src[r], :] if src[r] <= -2 (row of the concatenated image features), zeros if src[r] == -1 (padding).
+ * src is a DEVICE int64 array built from the index plan (integer host logic, slime_amd/model/llava_arch.py).
+ * Equal source / destination dtypes are copied bit for bit.  H * sizeof(out element) must be a multiple of 16. */
+int slime_splice_rows(const void* table, int table_dtype, long table_rows, const void* feats, int feats_dtype,
+                      long feat_rows, const int64_t* src, void* out, int out_dtype, long rows, int H, void* stream);
+
+/* Rotary position embedding, in place, on the first n_rot_heads heads (head_dim 128) of every row of a packed qkv buffer
+ * (row stride in elements): HF apply_rotary_pos_emb / rotate_half as called at llama_flash_attn_monkey_patch.py:51-54,
+ * angle = (float)pos[row] * inv_freq[i], i < 64 (inv_freq: DEVICE fp32 [64], computed by the host exactly as
+ * LlamaRotaryEmbedding does).  The first n_q_heads heads are additionally multiplied by q_scale (the attention kernels
+ * expect q pre-scaled by head_dim^-0.5 * log2 e). */
+int slime_rope(void* qkv, long row_stride, const int32_t* pos, long rows, int n_rot_heads, int n_q_heads, int head_dim,
+               const float* inv_freq, float q_scale, int dtype, void* stream);
+
+/* Causal grouped-query attention over the un-padded tokens of every sequence (llama_flash_attn_monkey_patch.py:65-90:
+ * repeat_kv + unpad_input + flash_attn_unpadded_qkvpacked_func(causal=True) + pad_input): query head h uses kv head
+ * h / (n_heads / n_kv_heads); sequence b attends within its token range [kv_start[b], kv_start[b] + kv_len[b]) (NULL:
+ * the whole sequence), query i sees keys <= i; output rows outside the range are zero.  Addressing as slime_attention
+ * (q pre-scaled by head_dim^-0.5 * log2 e, RoPE already applied); head_dim 128. */
+int slime_prefill_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v,
+                            long v_bs, long v_rs, void* o, long o_bs, long o_rs, int batch, int n_heads, int n_kv_heads,
+                            int head_dim, int S, const int32_t* kv_start, const int32_t* kv_len, int dtype, void* stream);
+
+/* LlamaAttention.forward as patched by llava/train/llama_flash_attn_monkey_patch.py:16-93 (no KV cache: prefill). */
+typedef struct {
+    int hidden, n_heads, n_kv_heads, head_dim, dtype;
+    const void*  w_qkv;                     /* T   [(n_heads + 2 n_kv_heads) * head_dim, hidden]: q_proj, k_proj, v_proj rows */
+    const void*  w_o;                       /* T   [hidden, n_heads * head_dim]                                               */
+    const float* inv_freq;                  /* f32 [head_dim / 2]                                                             */
+} slime_llama_attn_desc;
+
+size_t slime_llama_attn_workspace_bytes(const slime_llama_attn_desc* d, int batch, int S);
+
+/* hidden T [batch*S, hidden], position_ids int32 [batch*S] -> out [batch*S, hidden] (T or fp32). */
+int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
+                             const int32_t* kv_start, const int32_t* kv_len, int batch, int S, void* out, int out_dtype,
+                             void* ws, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,11 @@ class MlpDesc(C.Structure):
                 ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p)]
 
 
+class LlamaAttnDesc(C.Structure):
+    _fields_ = [("hidden", c_int), ("n_heads", c_int), ("n_kv_heads", c_int), ("head_dim", c_int), ("dtype", c_int),
+                ("w_qkv", c_void_p), ("w_o", c_void_p), ("inv_freq", c_void_p)]
+
+
 class Probe(C.Structure):
     _fields_ = [("layer", c_int), ("kernel", c_int), ("start", c_void_p), ("stop", c_void_p)]
 
@@ -103,6 +108,13 @@ _SIGNATURES = {
     "slime_adapter_workspace_bytes": (c_size_t, [_P(MlpDesc), _P(ResamplerDesc), _P(ResamplerDesc), c_int, c_int]),
     "slime_adapter_forward": (c_int, [_P(MlpDesc), _P(ResamplerDesc), c_void_p, c_int, _P(ResamplerDesc), c_void_p, c_int, c_int,
                                       c_int, c_int, c_int, c_void_p, c_int, c_long, c_void_p, c_size_t, c_void_p]),
+    "slime_splice_rows": (c_int, [c_void_p, c_int, c_long, c_void_p, c_int, c_long, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "slime_rope": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p]),
+    "slime_prefill_attention": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long,
+                                        c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "slime_llama_attn_workspace_bytes": (c_size_t, [_P(LlamaAttnDesc), c_int, c_int]),
+    "slime_llama_attn_forward": (c_int, [_P(LlamaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                         c_void_p, c_size_t, c_void_p]),
 }
 
 # diagnostic build only (libslime_hip_diag.so): process-global hooks, never exported by the product library

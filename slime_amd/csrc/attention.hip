@@ -583,6 +583,290 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
     }
 }
 
+// ================================================================================================
+// attn64r_kernel: ONE workgroup per (crop, head) -- K and V travel HBM/L2 -> LDS once instead of twice.
+//
+// attn64_kernel splits the 37 query sub-blocks of a CLIP head over two workgroups (3 sub-blocks per wave is what the
+// register file holds with double-buffered score tiles), so each of the two stages the full 2 x 76 KiB K/V panel: 304 KiB of
+// LDS-DMA per (crop, head) against ~25k cycles of MFMA work -- at the ~11 B/cycle a CU's load path sustains the staging is
+// as long as the arithmetic, and half of it sits exposed in front of each workgroup's first MFMA.  Here a workgroup keeps
+// the panel and walks its queries in TWO passes: pass 1 is attn64's pipeline on 3 sub-blocks per wave (24 of 37), pass 2
+// re-reads the resident panel for the remaining sub-blocks (2 or 1 per wave), with no DMA and no barrier at all.
+// The DMA is progressive: 64-row granules (one K and one V piece per wave per granule, issued in row order), and a wave
+// waits only for the granule it is about to touch (counted vmcnt + barrier), so the first MFMA starts after 16 KiB, not
+// 80 KiB, and the rest of the panel streams in under the arithmetic.
+// ================================================================================================
+template <typename T, int NSUB, bool RESIDENT>
+__device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
+    constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608, NW = 8;
+    constexpr int NG = 10;                                 // 64-row DMA granules (the last one is half empty: rows 576..607)
+    constexpr float RESCALE_TH = 8.0f;
+    char* Klds = smem;
+    char* Vlds = smem + KC * RB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+
+    u32x4 qf[NSUB > 0 ? NSUB : 1][KS];
+    if constexpr (NSUB > 0) {
+        const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                qf[s][ks] = *reinterpret_cast<const u32x4*>(qbase + ((size_t)qr * a.q_rs + ks * 32 + g * 8) * 2);
+        }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[s][ks]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ordinary loads retired before any LDS-DMA is in flight
+
+    if constexpr (!RESIDENT) {
+        const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
+        const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
+        const int lrow = lane >> 3, cpos = lane & 7;
+        const int kchunk = cpos ^ lrow;
+        const int vchunk = cpos ^ (((lrow >> 1) & 1) << 2);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            // granule gi = pieces 8 gi .. 8 gi + 7; the last granule has 4 pieces: waves 4..7 repeat them (same bytes to the
+            // same place) so that every wave has issued exactly 2 (gi + 1) DMAs after granule gi -- the counted waits below
+            int piece = gi * NW + wave;
+            if (piece >= KC / 8) piece -= 4;
+            const int row = min(piece * 8 + lrow, a.n_kv - 1);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
+                                             LDS_PTR(Klds + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(vbase + ((size_t)row * a.v_rs) * 2 + vchunk * 16),
+                                             LDS_PTR(Vlds + piece * 1024), 16, 0, 0);
+        }
+    }
+    // granule gi has landed for THIS wave when at most 2 (NG - 1 - gi) of its DMAs are outstanding; the barrier extends that
+    // to every wave's pieces.  Called by every wave of the workgroup for gi = 0, 1, 2, ... in order (uniform control flow).
+    auto granule_ready = [&](int gi) {
+        if constexpr (!RESIDENT) {
+            switch (gi) {
+                case 0: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto before_step = [&](int st) { if ((st & 1) == 0) granule_ready(st >> 1); };   // step st reads rows 32 st .. 32 st + 31
+
+    const int steps = (a.n_kv + 31) >> 5;
+    if constexpr (NSUB == 0) {
+        if constexpr (!RESIDENT) {
+            for (int st = 0; st < steps; ++st) before_step(st);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        return;
+    } else {
+        f32x4 o[NSUB][DT + 1], cinit[NSUB];
+        float m_run[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            m_run[s] = 0.f;
+            cinit[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d <= DT; ++d) o[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const unsigned one2 = T::pack2(1.0f, 1.0f);
+        const unsigned onew = (li == 0) ? one2 : 0u;
+        const u32x4 ones = {onew, onew, onew, onew};
+        unsigned kptr[KS], vptr[2];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kptr[ks] = lds_addr(Klds) + li * RB + (((ks * 4 + g) ^ (lane & 7)) << 4);
+        {
+            const int vrow = 4 * g + (li >> 2);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                vptr[hh] = lds_addr(Vlds) + vrow * RB + (((4 * hh + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4);
+        }
+        auto qk = [&](f32x4 (&sc)[NSUB][2]) {
+            u32x4 kf[2][KS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = t == 0 ? lds_b128_asm<0>(kptr[ks]) : lds_b128_asm<16 * RB>(kptr[ks]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], ks == 0 ? cinit[s] : sc[s][t]);
+        };
+        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], f32x4 (&nxt)[NSUB][2], bool has_next, bool masked) {
+            u32x2 v0[DT], v1[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1]) : lds_tr16_asm<0>(vptr[dt >> 1]);
+                v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1]) : lds_tr16_asm<16 * RB>(vptr[dt >> 1]);
+            }
+            vptr[0] += 32 * RB; vptr[1] += 32 * RB;
+            if (masked) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dead = st * 32 + t * 16 + 4 * g + r >= a.n_kv;
+#pragma unroll
+                        for (int s = 0; s < NSUB; ++s) sc[s][t][r] = dead ? -INFINITY : sc[s][t][r];
+                    }
+            }
+            float mc[NSUB];
+            bool need = false;
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
+                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
+                mx = __builtin_fmaxf(mx, sc[s][1][3]);
+                mc[s] = mx;
+                need |= mx > RESCALE_TH;
+            }
+            if (__builtin_amdgcn_ballot_w64(need) != 0 || st == 0) {
+#pragma unroll
+                for (int s = 0; s < NSUB; ++s) {
+                    float d = rows_allmax(mc[s]);
+                    d = st == 0 ? d : __builtin_fmaxf(d, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+                    for (int dd = 0; dd <= DT; ++dd) o[s][dd] *= alpha;
+                    m_run[s] += d;
+                    const float c = -m_run[s];
+                    cinit[s] = f32x4{c, c, c, c};
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            sc[s][t][r] -= d;
+                            if (has_next) nxt[s][t][r] -= d;
+                        }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
+                                                   "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
+            u32x4 vf[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[dt] = u32x4{v0[dt][0], v0[dt][1], v1[dt][0], v1[dt][1]};
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                float p[8];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(sc[s][t][r]);
+                const u32x4 pf = pack8<T>(p);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
+                o[s][DT] = T::mfma16(ones, pf, o[s][DT]);
+            }
+        };
+
+        f32x4 sA[NSUB][2], sB[NSUB][2];
+        const bool ragged = (a.n_kv & 31) != 0;
+        before_step(0);
+        qk(sA);
+        int st = 0;
+        for (; st + 2 < steps; st += 2) {
+            qk(sB);                                          // step st+1: same granule as step st
+            softmax_pv(st, sA, sB, true, false);
+            before_step(st + 2);
+            qk(sA);
+            softmax_pv(st + 1, sB, sA, true, false);
+        }
+        if (st + 2 == steps) {
+            qk(sB);
+            softmax_pv(st, sA, sB, true, false);
+            softmax_pv(st + 1, sB, sA, false, ragged);
+        } else {
+            softmax_pv(st, sA, sB, false, ragged);
+        }
+        if constexpr (!RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // granules beyond the last step (short n_kv)
+
+        char* obase = a.o + ((size_t)b * a.o_bs + (size_t)h * DH) * 2;
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) {
+            const float inv = 1.0f / rows_allsum(o[s][DT][0]);
+            const int qr = (sb0 + s) * 16 + li;
+            if (qr < a.n_q) {
+#pragma unroll
+                for (int p = 0; p < DT / 2; ++p) {
+                    float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
+                                  o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
+                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 8, P1 = 3 * NW;                        // pass 1: <= 3 sub-blocks per wave
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_sb = (a.n_q + 15) >> 4;
+    const int wg_sb0 = blockIdx.z * a.sb_per_wg;
+    const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);      // <= 5 * NW
+    const int n1 = min(nsb, P1), n2 = nsb - n1;               // pass 2: <= 2 per wave
+    {
+        const int base = n1 / NW, rem = n1 % NW;
+        const int cnt = base + (wave < rem ? 1 : 0);
+        const int sb0 = wg_sb0 + wave * base + min(wave, rem);
+        switch (cnt) {
+            case 0: attn64r_pass<T, 0, false>(a, smem, b, h, sb0); break;
+            case 1: attn64r_pass<T, 1, false>(a, smem, b, h, sb0); break;
+            case 2: attn64r_pass<T, 2, false>(a, smem, b, h, sb0); break;
+            default: attn64r_pass<T, 3, false>(a, smem, b, h, sb0); break;
+        }
+    }
+    if (n2 > 0) {
+        // every wave left pass 1 behind the last granule's barrier: the whole panel is resident and read-only from here on.
+        // The waves that got the most work in pass 1 (low ids when n1 % 8 != 0) get the least here.
+        const int base = n2 / NW, rem = n2 % NW;
+        const int rw = NW - 1 - wave;
+        const int cnt = base + (rw < rem ? 1 : 0);
+        const int sb0 = wg_sb0 + n1 + rw * base + min(rw, rem);
+        switch (cnt) {
+            case 0: break;
+            case 1: attn64r_pass<T, 1, true>(a, smem, b, h, sb0); break;
+            default: attn64r_pass<T, 2, true>(a, smem, b, h, sb0); break;
+        }
+    }
+}
+
+template <typename T>
+static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
+    AttnArgs a = a0;
+    constexpr int LDS = 2 * 608 * 128;
+    auto kern = attn64r_kernel<T>;
+    SLIME_SET_LDS_ONCE(kern, LDS, "attention");
+    const int total_sb = (a.n_q + 15) / 16;
+    const int qsplit = (total_sb + 39) / 40;                  // <= 3 + 2 sub-blocks per wave, 8 waves
+    a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
+    hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(512), LDS, stream, a);
+    SLIME_CHECK_LAUNCH("attention64r");
+    return SLIME_OK;
+}
+
 template <typename T>
 static int launch_attn64(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
@@ -623,10 +907,17 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
                (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg, g_attn_abl};
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 0 && !g_attn_dbg) {
-        // CLIP shape: software-pipelined kernel (the DMA split assumes the second half is non-empty)
+        // CLIP shape: software-pipelined kernel, one workgroup per (crop, head), K/V staged once (granule DMA)
+        if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
+        return launch_attn64r<BF16>(a, batch, s);
+    }
+#ifdef SLIME_DIAG
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 2 && !g_attn_dbg) {
+        // the round-1 kernel (two workgroups per (crop, head), two DMA halves), kept for A/B
         if (dtype == SLIME_F16) return launch_attn64<F16>(a, batch, s);
         return launch_attn64<BF16>(a, batch, s);
     }
+#endif
     if (head_dim == 64) {
         // K+V resident up to 608 rows (CLIP S = 577); longer sequences stream in 608-row chunks.
         if (dtype == SLIME_F16) return launch_attn<F16, 64, 608, 8, 5>(a, batch, s);

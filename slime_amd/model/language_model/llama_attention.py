@@ -1,0 +1,91 @@
+"""Llama-3 prefill self-attention on the HIP path: the counterpart of llava/train/llama_flash_attn_monkey_patch.py.
+
+The reference swaps ``LlamaAttention.forward`` for a flash-attn version (``replace_llama_attn_with_flash_attn``, :105-115);
+``replace_llama_attn_with_hip_attn`` does the same with ``slime_llama_attn_forward`` (fused q/k/v projection GEMM, RoPE,
+causal grouped-query attention over the un-padded tokens, o_proj GEMM -- slime_amd/csrc/prefill.hip).  ``HipLlamaAttention``
+is the standalone module form (HF parameter names ``q_proj`` / ``k_proj`` / ``v_proj`` / ``o_proj``, no biases) used by the
+tests and bench.py.  Prefill only: a KV cache (``past_key_value``) is outside this row of SURVEY.md section 8 and raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+
+
+class HipLlamaAttention(nn.Module):
+    def __init__(self, hidden_size: int = 4096, num_heads: int = 32, num_key_value_heads: int = 8, head_dim: int = 128,
+                 rope_theta: float = 500000.0, compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__()
+        if head_dim != 128:
+            raise NotImplementedError("the HIP prefill attention is built for head_dim 128 (Llama-3)")
+        self.hidden_size, self.num_heads, self.num_key_value_heads, self.head_dim = hidden_size, num_heads, num_key_value_heads, head_dim
+        self.num_key_value_groups = num_heads // num_key_value_heads
+        self.rope_theta = rope_theta
+        self.compute_dtype = compute_dtype
+        self.q_proj = nn.Linear(hidden_size, num_heads * head_dim, bias=False)
+        self.k_proj = nn.Linear(hidden_size, num_key_value_heads * head_dim, bias=False)
+        self.v_proj = nn.Linear(hidden_size, num_key_value_heads * head_dim, bias=False)
+        self.o_proj = nn.Linear(num_heads * head_dim, hidden_size, bias=False)
+        self._packed: Dict = {}
+
+    def _apply(self, fn, *a, **kw):
+        self._packed.clear()
+        return super()._apply(fn, *a, **kw)
+
+    def _load_from_state_dict(self, *a, **kw):
+        self._packed.clear()
+        return super()._load_from_state_dict(*a, **kw)
+
+    def packed(self, dtype: torch.dtype) -> ops.PackedLlamaAttention:
+        key = (dtype, str(self.q_proj.weight.device))
+        if key not in self._packed:
+            self._packed[key] = ops.pack_llama_attention(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight,
+                                                         self.o_proj.weight, self.num_heads, self.num_key_value_heads, dtype,
+                                                         self.q_proj.weight.device, self.rope_theta)
+        return self._packed[key]
+
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None, past_key_value=None, output_attentions: bool = False,
+                use_cache: bool = False, **_):
+        """Signature and return triple of the patched forward (llama_flash_attn_monkey_patch.py:16-24,92):
+        ``attention_mask`` is the [B, S] key-padding mask (the patch disables HF's 4-D mask expansion, :97-102)."""
+        if past_key_value is not None or use_cache:
+            raise NotImplementedError("HipLlamaAttention implements the prefill pass (no KV cache)")
+        dt = hidden_states.dtype if hidden_states.dtype in (torch.bfloat16, torch.float16) else self.compute_dtype
+        out = ops.llama_attention_forward(self.packed(dt), hidden_states, position_ids, attention_mask, hidden_states.dtype)
+        return out, None, None
+
+
+def replace_llama_attn_with_hip_attn():
+    """Patch HF ``LlamaAttention.forward`` like ``replace_llama_attn_with_flash_attn`` does (the key-padding mask must reach
+    the attention un-expanded, as in the reference's ``_prepare_decoder_attention_mask`` override)."""
+    import transformers
+    from transformers.models.llama import modeling_llama as M
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                use_cache=False, **kw):
+        if past_key_value is not None or use_cache:
+            raise NotImplementedError("slime_amd patches the prefill pass only")
+        cfg = self.config
+        key = "_slime_packed"
+        dt = hidden_states.dtype if hidden_states.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+        cache = self.__dict__.setdefault(key, {})
+        k = (dt, str(self.q_proj.weight.device))
+        if k not in cache:
+            cache[k] = ops.pack_llama_attention(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.o_proj.weight,
+                                                cfg.num_attention_heads, cfg.num_key_value_heads, dt, self.q_proj.weight.device,
+                                                float(getattr(cfg, "rope_theta", 500000.0)))
+        if attention_mask is not None and attention_mask.dim() != 2:
+            raise ValueError("expected the [B, S] key-padding mask (llama_flash_attn_monkey_patch.py:97-102)")
+        out = ops.llama_attention_forward(cache[k], hidden_states, position_ids, attention_mask, hidden_states.dtype)
+        return out, None, None
+
+    if hasattr(M.LlamaModel, "_prepare_decoder_attention_mask"):
+        M.LlamaModel._prepare_decoder_attention_mask = lambda self, attention_mask, *a, **k: attention_mask
+    M.LlamaAttention.forward = forward
+    return transformers

@@ -32,7 +32,7 @@ from .multimodal_encoder.builder import build_vision_tower
 from .multimodal_projector.builder import build_vision_projector, GatedBlock, _operand_dtype
 from .multimodal_resampler.builder import build_vision_sampler
 from .. import ops
-from ..constants import IMAGE_TOKEN_INDEX
+from ..constants import IMAGE_TOKEN_INDEX, IGNORE_INDEX
 from ..mm_utils import get_anyres_image_grid_shape
 
 
@@ -99,6 +99,55 @@ def _fused_adapter(model, images: torch.Tensor, layout, out_dtype: torch.dtype, 
     post = model.sampler.post_qformer.packed(feats.shape[1], T) if n_local else None
     return ops.adapter_forward(model.mm_projector.packed(T), post, feats, B, n_local, nw, nh, merge,
                                int(model.mm_projector.learnable_gated), out_dtype, out)
+
+
+def splice_plan(input_ids, attention_mask, labels, feat_lens, max_length=None, padding_side: str = "right"):
+    """Index plan of ``prepare_inputs_labels_for_multimodal`` (llava_arch.py:362-459), integer host logic on numpy arrays.
+    ``input_ids`` [B, L] int64 (IMAGE_TOKEN_INDEX marks an image), ``attention_mask`` [B, L] or None, ``labels`` [B, L] or
+    None, ``feat_lens[j]`` = token rows of image feature j (consumed in order of appearance; a sequence without an image
+    token still consumes one feature, of which it uses zero rows: :377-385).
+    Returns int64 arrays [B, max_len]: ``src`` (>= 0 token id, -2 - k row k of the concatenated features, -1 padding),
+    ``labels`` (IGNORE_INDEX on image and padding rows), ``mask``, ``position_ids``."""
+    import numpy as np
+    ids = np.asarray(input_ids, dtype=np.int64)
+    B = ids.shape[0]
+    am = np.ones_like(ids, dtype=bool) if attention_mask is None else np.asarray(attention_mask) != 0
+    lb = np.full_like(ids, IGNORE_INDEX) if labels is None else np.asarray(labels, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(np.asarray(feat_lens, dtype=np.int64))])
+    seqs, labs, img = [], [], 0
+    for b in range(B):
+        t, y = ids[b][am[b]], lb[b][am[b]]                                  # :366-368 drop padding through the mask
+        where = np.nonzero(t == IMAGE_TOKEN_INDEX)[0]
+        if where.size == 0:                                                 # :376-385
+            if img >= len(feat_lens):
+                raise ValueError("fewer image features than sequences / image tokens")
+            seqs.append(t); labs.append(y); img += 1
+            continue
+        if img + where.size > len(feat_lens):
+            raise ValueError("fewer image features than image tokens")
+        ps, pl, prev = [], [], 0
+        for w in where:                                                     # :387-411
+            ps.append(t[prev:w]); pl.append(y[prev:w])
+            n = int(feat_lens[img])
+            ps.append(-2 - (starts[img] + np.arange(n, dtype=np.int64)))
+            pl.append(np.full(n, IGNORE_INDEX, dtype=np.int64))
+            img += 1
+            prev = w + 1
+        ps.append(t[prev:]); pl.append(y[prev:])
+        seqs.append(np.concatenate(ps)); labs.append(np.concatenate(pl))
+    if max_length is not None:                                              # :420-424
+        seqs = [q[:max_length] for q in seqs]
+        labs = [q[:max_length] for q in labs]
+    max_len = max(q.shape[0] for q in seqs)                                 # :427
+    src = np.full((B, max_len), -1, dtype=np.int64)
+    lab = np.full((B, max_len), IGNORE_INDEX, dtype=np.int64)
+    mask = np.zeros((B, max_len), dtype=np.int64)
+    pos = np.zeros((B, max_len), dtype=np.int64)
+    for b, (q, y) in enumerate(zip(seqs, labs)):                            # :435-455
+        n = q.shape[0]
+        sl = slice(max_len - n, max_len) if padding_side == "left" else slice(0, n)
+        src[b, sl], lab[b, sl], mask[b, sl], pos[b, sl] = q, y, 1, np.arange(n)
+    return src, lab, mask, pos
 
 
 class SlimeMetaModel:
@@ -235,6 +284,62 @@ class SlimeMetaForCausalLM(ABC):
 
         feats = tower(images, out_dtype=torch.float32)
         return model.mm_projector(feats, out_dtype=out_dtype), split_sizes
+
+
+    # ------------------------------------------------------------------ splice (the step after the hot path)
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images,
+                                             image_sizes=None, images_mask=None):
+        """Signature, branches and return tuple of llava_arch.py:274-459.  The visual features come from ``encode_images``
+        above; the splice itself is an integer plan on the host (``splice_plan``: token ids are a few hundred ints) and ONE
+        device launch (``slime_splice_rows``) that writes the whole padded [B, max_len, H] embedding tensor -- embedding
+        lookup, image rows, zero padding -- where the reference runs per-sequence embed / split / cat / stack."""
+        vision_tower = self.get_vision_tower()
+        if vision_tower is None or images is None or input_ids.shape[1] == 1:
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+        merge_type = getattr(self.config, "mm_patch_merge_type", "flat")
+        if type(images) is list or images.ndim == 5:
+            if type(images) is list:
+                images = [x.unsqueeze(0) if x.ndim == 3 else x for x in images]
+            concat_images = torch.cat([im for im in images], dim=0)
+            split_sizes = [im.shape[0] for im in images]
+            feats, split_sizes = self.encode_images(concat_images, input_ids, split_sizes, attention_mask, images_mask, image_sizes,
+                                                    labels=labels)
+            if type(feats) is not list:
+                feats = list(torch.split(feats, split_sizes, dim=0))
+            flat = []
+            for f in feats:
+                if f.dim() == 3 and f.shape[0] == 1:                      # sampler branch: [1, 576 + 1 + k, H] (:254-255,322)
+                    flat.append(f[0])
+                elif merge_type == "flat":                                  # :290-291
+                    flat.append(f.flatten(0, 1))
+                elif merge_type.startswith("spatial"):
+                    raise NotImplementedError("LLaVA-NeXT style spatial merge of un-sampled crops (llava_arch.py:293-330) is outside "
+                                              "the SliME hot path: SliME merges inside encode_images (sampler branch)")
+                else:
+                    raise ValueError(f"Unexpected mm_patch_merge_type: {merge_type}")
+            feats = flat
+        else:
+            f, _ = self.encode_images(images, input_ids=input_ids, attention_mask=attention_mask, labels=labels)
+            feats = [x for x in f]
+        if getattr(self.config, "tune_mm_mlp_adapter", False) and getattr(self.config, "mm_use_im_start_end", False):
+            raise NotImplementedError
+
+        embed = self.get_model().embed_tokens
+        table = embed.weight
+        dev = table.device
+        src, lab, mask, pos = splice_plan(input_ids.detach().cpu().numpy(),
+                                          None if attention_mask is None else attention_mask.detach().cpu().numpy(),
+                                          None if labels is None else labels.detach().cpu().numpy(),
+                                          [f.shape[0] for f in feats], getattr(self.config, "tokenizer_model_max_length", None),
+                                          getattr(self.config, "tokenizer_padding_side", "right"))
+        B, T = src.shape
+        allf = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], 0).to(dev) if feats else None
+        out_dtype = table.dtype if table.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32
+        new_input_embeds = ops.splice_rows(table.detach(), allf, torch.from_numpy(src).reshape(-1).to(dev), out_dtype).view(B, T, -1)
+        new_labels = None if labels is None else torch.from_numpy(lab).to(labels.device, labels.dtype)
+        new_mask = None if attention_mask is None else torch.from_numpy(mask).to(attention_mask.device, attention_mask.dtype)
+        new_pos = None if position_ids is None else torch.from_numpy(pos).to(position_ids.device, position_ids.dtype)
+        return None, new_pos, new_mask, past_key_values, new_input_embeds, new_labels
 
 
 class _Cfg:

@@ -559,3 +559,101 @@ def router_topp(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.
         return torch.zeros((0,), dtype=torch.long, device=local_f.device)
     keep, cnt = router_select(router_scores(local_f, text, mask), topp, temp)
     return keep[: int(cnt.item())].long()
+
+
+# ------------------------------------------------------------------------------------------------
+# after the visual tokens: splice + Llama prefill attention
+# ------------------------------------------------------------------------------------------------
+
+def splice_rows(table: Optional[torch.Tensor], feats: Optional[torch.Tensor], src: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """out[r] = table[src[r]] (src >= 0) | feats[-2 - src[r]] (src <= -2) | 0 (src == -1); src int64 [rows] on the device.
+    One launch for the whole padded batch (llava_arch.py:343-459 builds it with per-sequence cat / split / stack)."""
+    lib = _lib.load()
+    _require_cuda(src, "src")
+    H = (table if table is not None else feats).shape[-1]
+    rows = src.numel()
+    out = torch.empty((rows, H), dtype=out_dtype, device=src.device)
+    t = None if table is None else table.contiguous()
+    f = None if feats is None or feats.numel() == 0 else feats.contiguous()
+    _lib.check(lib.slime_splice_rows(_ptr(t), dtype_code(t.dtype) if t is not None else 0, 0 if t is None else t.shape[0],
+                                     _ptr(f), dtype_code(f.dtype) if f is not None else 0, 0 if f is None else f.shape[0],
+                                     _ptr(src.contiguous()), out.data_ptr(), dtype_code(out_dtype), rows, H, _stream()),
+               "slime_splice_rows")
+    return out
+
+
+@dataclass
+class PackedLlamaAttention:
+    hidden: int
+    n_heads: int
+    n_kv_heads: int
+    head_dim: int
+    dtype: torch.dtype
+    tensors: Dict[str, torch.Tensor]
+    desc: "_lib.LlamaAttnDesc"
+    ws: Workspace = field(default_factory=Workspace)
+
+
+def llama_inv_freq(head_dim: int, theta: float) -> torch.Tensor:
+    """fp32 inverse frequencies exactly as LlamaRotaryEmbedding computes them (default rope type)."""
+    return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+
+
+def pack_llama_attention(wq, wk, wv, wo, n_heads: int, n_kv_heads: int, dtype: torch.dtype, device,
+                         rope_theta: float = 500000.0) -> PackedLlamaAttention:
+    """q_proj / k_proj / v_proj / o_proj weights (nn.Linear layout, no biases) -> one fused [q|k|v] operand + o."""
+    D = wq.shape[1]
+    dh = wq.shape[0] // n_heads
+    if dh != 128 or wk.shape[0] != n_kv_heads * dh or wv.shape[0] != n_kv_heads * dh or tuple(wo.shape) != (D, n_heads * dh):
+        raise ValueError("pack_llama_attention: head_dim must be 128 and the projection shapes consistent")
+
+    def tt(t):
+        return t.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous()
+
+    T = {"w_qkv": tt(torch.cat([wq.detach().float().cpu(), wk.detach().float().cpu(), wv.detach().float().cpu()], 0)),
+         "w_o": tt(wo), "inv_freq": llama_inv_freq(dh, rope_theta).to(device)}
+    d = _lib.LlamaAttnDesc()
+    d.hidden, d.n_heads, d.n_kv_heads, d.head_dim, d.dtype = D, n_heads, n_kv_heads, dh, dtype_code(dtype)
+    for k, v in T.items():
+        setattr(d, k, v.data_ptr())
+    return PackedLlamaAttention(D, n_heads, n_kv_heads, dh, dtype, T, d)
+
+
+def token_ranges(attention_mask: Optional[torch.Tensor]):
+    """Key-padding mask [B, S] -> (start, length) int32 [B] of the token run of every sequence.  Prefill masks are
+    contiguous runs (right or left padding, llava_arch.py:435-455); anything else is rejected.  Host-side check: one D2H."""
+    if attention_mask is None:
+        return None, None
+    m = attention_mask.ne(0)
+    length = m.sum(1)
+    start = torch.where(length > 0, m.to(torch.int8).argmax(1), torch.zeros_like(length))
+    S = m.shape[1]
+    idx = torch.arange(S, device=m.device)[None]
+    run = (idx >= start[:, None]) & (idx < (start + length)[:, None])
+    if not bool(torch.equal(run, m)):
+        raise ValueError("attention_mask must mark one contiguous run of tokens per sequence (left or right padding)")
+    return start.to(torch.int32).contiguous(), length.to(torch.int32).contiguous()
+
+
+def llama_attention_forward(pa: PackedLlamaAttention, hidden: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                            attention_mask: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """hidden [B, S, D] -> [B, S, D]: q/k/v projection, RoPE, causal GQA attention over the un-padded tokens, o_proj."""
+    lib = _lib.load()
+    _require_cuda(hidden, "hidden")
+    B, S, D = hidden.shape
+    assert D == pa.hidden
+    x = hidden.to(pa.dtype).contiguous()
+    if position_ids is None:
+        position_ids = torch.arange(S, device=x.device)[None].expand(B, S)
+    pos = position_ids.to(device=x.device, dtype=torch.int32).contiguous()
+    start, length = token_ranges(None if attention_mask is None else attention_mask.to(x.device))
+    out_dtype = out_dtype or hidden.dtype
+    kernel_out = torch.float32 if out_dtype == torch.float32 else pa.dtype
+    out = torch.empty((B, S, D), dtype=kernel_out, device=x.device)
+    need = lib.slime_llama_attn_workspace_bytes(C.byref(pa.desc), B, S)
+    ws = pa.ws.get(need, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_llama_attn_forward(C.byref(pa.desc), x.data_ptr(), pos.data_ptr(), _ptr(start), _ptr(length), B, S,
+                                            out.data_ptr(), dtype_code(kernel_out), base, ws.numel() - (base - ws.data_ptr()),
+                                            _stream()), "slime_llama_attn_forward")
+    return out if out.dtype == out_dtype else out.to(out_dtype)

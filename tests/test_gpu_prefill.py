@@ -1,0 +1,178 @@
+"""GPU parity tests of SURVEY.md section 8 row f-2 (BASELINE configs 4 / 5): the visual-token splice (bit-exact) and the Llama-3
+prefill attention (RoPE + causal GQA + projections) against oracle/prefill_oracle.py and the reference-generated vectors of
+tests/golden/prefill.npz.  Tolerances as everywhere (rel-L2 vs fp32): per stage fp16 3e-3, bf16 1.5e-2."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+import prefill_fixture as F
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 3e-3, torch.bfloat16: 1.5e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from slime_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ splice
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_splice_kernel_bit_exact_vs_reference(dev, name, dtype):
+    """One launch reproduces the reference's new_input_embeds bit for bit (same-dtype rows are raw copies; the reference's
+    fp32 vectors rounded to a 16-bit table / feature dtype are still exact copies of the rounded inputs)."""
+    from slime_amd import ops
+    from slime_amd.model.llava_arch import splice_plan
+    c = F.splice_case(F.load(), name)
+    am = None if c["attention_mask"] is None else c["attention_mask"].numpy()
+    lb = None if c["labels"] is None else c["labels"].numpy()
+    src, _, _, _ = splice_plan(c["input_ids"].numpy(), am, lb, [f.shape[0] for f in c["feats"]], c["max_length"], c["padding_side"])
+    table = c["table"].to(dtype).to(dev)
+    allf = torch.cat(c["feats"], 0).to(dtype).to(dev)
+    out = ops.splice_rows(table, allf, torch.from_numpy(src).reshape(-1).to(dev), dtype).view(*src.shape, -1)
+    s = torch.from_numpy(src)
+    want = torch.zeros(src.shape + (table.shape[1],), dtype=dtype)
+    want[s >= 0] = table.cpu()[s[s >= 0]]
+    want[s <= -2] = allf.cpu()[-2 - s[s <= -2]]
+    assert torch.equal(out.cpu(), want)
+    if dtype == torch.float32:
+        assert torch.equal(out.cpu(), c["out_embeds"])
+    # mixed dtypes: fp32 features into a bf16 table's output (cast path)
+    mixed = ops.splice_rows(c["table"].to(torch.bfloat16).to(dev), torch.cat(c["feats"], 0).to(dev),
+                            torch.from_numpy(src).reshape(-1).to(dev), torch.bfloat16).view(*src.shape, -1)
+    assert torch.equal(mixed.cpu(), c["out_embeds"].to(torch.bfloat16))
+
+
+def test_prepare_inputs_labels_for_multimodal_end_to_end(dev):
+    """The reference-shaped method on the tiny encoder: encode_images (HIP tower + adapter + router) feeds the splice;
+    checked against the oracle's splice of the very same visual tokens, and the None-passing contract of :456-470."""
+    import torch.nn as nn
+    from oracle import prefill_oracle as P
+    from test_gpu_modules import _tiny_encoder
+    embed = nn.Embedding(2048, 256)
+    embed.weight.data.copy_(torch.randn(2048, 256, generator=torch.Generator().manual_seed(3)) * 0.5)
+    enc, _, _ = _tiny_encoder(dev, torch.bfloat16, embed=embed)
+    from slime_amd import weights as W
+    px = [W.synthetic_pixels(3, seed=61).to(dev), W.synthetic_pixels(3, seed=62).to(dev)]
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(1, 2000, (2, 12), generator=g)
+    ids[0, 3] = -200
+    ids[1, 0] = -200
+    am = torch.ones_like(ids)
+    am[1, 9:] = 0
+    lab = ids.clone()
+    ids_d, am_d, lab_d = ids.to(dev), am.to(dev), lab.to(dev)
+    sizes = [(336, 336), (336, 336)]
+    feats, _ = enc.encode_images(torch.cat(px, 0), ids_d, [3, 3], am_d, None, sizes, labels=lab_d)
+    out = enc.prepare_inputs_labels_for_multimodal(ids_d, None, am_d, None, lab_d, px, image_sizes=sizes)
+    none_ids, pos, mask, pkv, emb, labels = out
+    assert none_ids is None and pos is None and pkv is None
+    want, wl, wm, _ = P.splice(embed.weight.detach().cpu(), [f[0].float().cpu() for f in feats], ids, am, lab)
+    assert emb.shape == want.shape and torch.equal(emb.float().cpu(), want)
+    assert torch.equal(labels.cpu(), wl) and torch.equal(mask.cpu(), wm)
+    # text-only step (decode: one token) and image-free call return the inputs untouched
+    one = enc.prepare_inputs_labels_for_multimodal(ids_d[:, :1], None, am_d[:, :1], None, None, px)
+    assert one[0] is not None and one[4] is None
+
+
+# ------------------------------------------------------------------------------------------------ RoPE / attention
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_rope_kernel_vs_oracle(dev, dtype):
+    from slime_amd import ops, _lib
+    from oracle import prefill_oracle as P
+    lib = _lib.load()
+    B, S, HQ, HKV = 2, 77, 8, 2
+    g = torch.Generator().manual_seed(4)
+    qkv = torch.randn(B, S, (HQ + 2 * HKV) * 128, generator=g).to(dtype)
+    pos = torch.randint(0, 8000, (B, S), generator=g)
+    inv = ops.llama_inv_freq(128, 500000.0)
+    cos, sin = P.rope_tables(pos, 128, 500000.0)
+    x = qkv.float().view(B, S, HQ + 2 * HKV, 128).transpose(1, 2)
+    scale = 128 ** -0.5 * ops.LOG2E
+    want = x.clone()
+    want[:, :HQ + HKV] = P.apply_rope(x[:, :HQ + HKV], cos, sin)
+    want[:, :HQ] *= scale
+    d = qkv.to(dev).clone()
+    _lib.check(lib.slime_rope(d.data_ptr(), d.shape[-1], pos.to(torch.int32).to(dev).data_ptr(), B * S, HQ + HKV, HQ, 128,
+                              inv.to(dev).data_ptr(), scale, ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream))
+    got = d.float().cpu().view(B, S, HQ + 2 * HKV, 128).transpose(1, 2)
+    assert rel_l2(got[:, :HQ + HKV], want[:, :HQ + HKV]) < {torch.bfloat16: 4e-3, torch.float16: 6e-4}[dtype]
+    assert torch.equal(got[:, HQ + HKV:], x[:, HQ + HKV:])                       # v untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode", ["nopad", "right", "left"])
+def test_llama_attention_vs_hf_golden_and_oracle(dev, dtype, mode):
+    """slime_llama_attn_forward (projection GEMM + RoPE + causal GQA + o_proj) vs the HF LlamaAttention vectors and, on
+    the full tensor, vs the oracle; rows at padded positions are exactly zero (pad_input)."""
+    from slime_amd.model.language_model import HipLlamaAttention
+    from oracle import prefill_oracle as P
+    g = F.load()
+    (D, HQ, HKV, S, B), w, hidden = F.llama_inputs(g)
+    m = HipLlamaAttention(D, HQ, HKV, 128, float(g["llama_theta"][0]), compute_dtype=dtype)
+    m.load_state_dict({f"{k}.weight": v for k, v in w.items()})
+    m.to(dev)
+    mask = torch.from_numpy(g[f"llama_{mode}_mask"])
+    pos = torch.from_numpy(g[f"llama_{mode}_pos"])
+    out, _, _ = m(hidden.to(dev), attention_mask=None if mode == "nopad" else mask.to(dev), position_ids=pos.to(dev))
+    assert out.dtype == torch.float32 and out.shape == (B, S, D)
+    out = out.cpu()
+    assert rel_l2(out[:, ::3, ::7], g[f"llama_{mode}_out"]) < TOL[dtype]
+    ref = P.llama_attention_forward(hidden, w["q_proj"], w["k_proj"], w["v_proj"], w["o_proj"], HQ, HKV, pos,
+                                    None if mode == "nopad" else mask, float(g["llama_theta"][0]))
+    assert rel_l2(out, ref) < TOL[dtype]
+    worst = ((out - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6))[mask.bool()].max()
+    assert float(worst) < 6 * TOL[dtype], "no single token row far off (catches a wrong row hiding in the aggregate)"
+    if mode != "nopad":
+        assert float(out[mask == 0].abs().max()) == 0.0
+
+
+def test_prefill_attention_causality_and_group_mapping(dev):
+    """Size-independent properties at the Llama-3-8B shape (32 query / 8 kv heads, S = 1300): (i) causal -- changing tokens
+    after position t leaves rows <= t bit-identical; (ii) GQA -- the 4 query heads of a kv group given IDENTICAL queries
+    produce identical outputs, and a different kv head's keys do not leak in; (iii) a sequence's result does not depend on
+    what shares the batch with it."""
+    from slime_amd import ops
+    B, S, HQ, HKV = 2, 1300, 32, 8
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(8)
+    N = (HQ + 2 * HKV) * 128
+    qkv = (torch.randn(B, S, N, generator=g) * 0.5).to(dt).to(dev)
+    qkv[..., :HQ * 128] *= 0.1
+
+    def run(x, start=None, length=None):
+        lib = ops._lib.load()
+        o = torch.empty((x.shape[0], S, HQ * 128), dtype=dt, device=dev)
+        ops._lib.check(lib.slime_prefill_attention(x.data_ptr(), S * N, N, x.data_ptr() + HQ * 256, S * N, N,
+                                                  x.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                                  x.shape[0], HQ, HKV, 128, S, None if start is None else start.data_ptr(),
+                                                  None if length is None else length.data_ptr(), ops.dtype_code(dt),
+                                                  torch.cuda.current_stream().cuda_stream))
+        return o
+
+    base = run(qkv)
+    assert torch.isfinite(base.float()).all()
+    t = 700
+    mod = qkv.clone()
+    mod[:, t + 1:] = torch.randn(B, S - t - 1, N, generator=g).to(dt).to(dev)
+    assert torch.equal(run(mod)[:, :t + 1], base[:, :t + 1])                                   # (i)
+    same = qkv.clone()
+    same[..., :HQ * 128] = same[..., :128].repeat(1, 1, HQ)                                      # every q head = head 0's q
+    o = run(same).view(B, S, HQ, 128)
+    for h in range(1, 4):
+        assert torch.equal(o[:, :, h], o[:, :, 0])                                               # (ii) same kv group
+    assert not torch.equal(o[:, :, 4], o[:, :, 0])                                               #      next group: other keys
+    assert torch.equal(run(qkv[1:2].contiguous())[0], base[1])                                   # (iii)
+    # token ranges: left-padded sequence == the same tokens run without padding (RoPE already in the inputs)
+    start = torch.tensor([0, 300], dtype=torch.int32, device=dev)
+    length = torch.tensor([S, S - 300], dtype=torch.int32, device=dev)
+    ranged = run(qkv, start, length)
+    assert float(ranged[1, :300].float().abs().max()) == 0.0
+    alone = run(torch.cat([qkv[1:2, 300:], qkv[1:2, :300]], 1).contiguous(), torch.tensor([0], dtype=torch.int32, device=dev),
+                torch.tensor([S - 300], dtype=torch.int32, device=dev))
+    assert rel_l2(ranged[1, 300:].float(), alone[0, :S - 300].float()) < 4e-3      # same math; chunk boundaries differ -> rounding only

@@ -207,3 +207,26 @@ def test_resampler_pack_regenerates_nan_pos_embed():
         assert torch.isfinite(fixed.tensors[k].float()).all()
         assert torch.equal(fixed.tensors[k], want.tensors[k])
     assert torch.isfinite(good.tensors["q_proj"].float()).all()
+
+
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+def test_splice_plan_matches_reference(name):
+    """Row f-2, host half: the integer splice plan reproduces the reference's prepare_inputs_labels_for_multimodal outputs
+    (tests/golden/prefill.npz) -- labels, mask, position ids bit for bit, and the embeddings once the plan is applied."""
+    import prefill_fixture as F
+    from slime_amd.model.llava_arch import splice_plan
+    c = F.splice_case(F.load(), name)
+    am = None if c["attention_mask"] is None else c["attention_mask"].numpy()
+    lb = None if c["labels"] is None else c["labels"].numpy()
+    src, lab, mask, pos = splice_plan(c["input_ids"].numpy(), am, lb, [f.shape[0] for f in c["feats"]], c["max_length"], c["padding_side"])
+    allf = torch.cat(c["feats"], 0)
+    emb = torch.zeros(src.shape + (c["table"].shape[1],))
+    s = torch.from_numpy(src)
+    emb[s >= 0] = c["table"][s[s >= 0]]
+    emb[s <= -2] = allf[-2 - s[s <= -2]]
+    assert torch.equal(emb, c["out_embeds"])
+    if c["out_mask"] is not None:
+        assert np.array_equal(mask, c["out_mask"].numpy()) and np.array_equal(lab, c["out_labels"].numpy())
+        assert np.array_equal(pos, c["out_position_ids"].numpy())
+    with pytest.raises(ValueError, match="fewer image features"):
+        splice_plan(c["input_ids"].numpy(), am, lb, [f.shape[0] for f in c["feats"]][:-1], c["max_length"], c["padding_side"])
