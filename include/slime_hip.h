@@ -180,6 +180,18 @@ int slime_router_scores(const float* img, int T, const float* text, int L, const
 int slime_router_select(const float* scores, int T, float temp, float topp, int* keep_idx, int* keep_count,
                         float* probs_out, void* stream);
 
+/* Batched router for the B images of a step (one launch sequence, per-image results identical to the single calls):
+ * image b owns rows row_off[b] .. row_off[b] + n_rows[b] - 1 of img (row_off int64 / n_rows int32, DEVICE arrays -- the
+ * local-token rows of a fused [B, 576 + T, H] token buffer or a ragged concatenation); text fp32 [B, L, H], mask uint8
+ * [B, L] or NULL; scores / keep_idx are padded [B, T_max], keep_count [B]: ONE D2H read of keep_count serves the batch.
+ * ws: slime_router_batched_workspace_floats(B, L, H) floats. */
+size_t slime_router_batched_workspace_floats(int B, int L, int H);
+int slime_router_scores_batched(const float* img, const long long* row_off, const int* n_rows, int B, int T_max,
+                                const float* text, int L, const unsigned char* mask, int H, float* scores, float* ws,
+                                void* stream);
+int slime_router_select_batched(const float* scores, const int* n_rows, int B, int T_max, float temp, float topp,
+                                int* keep_idx, int* keep_count, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * CLIP vision tower (CLIPVisionTower.forward + feature_select, clip_encoder.py:36-58)
  * ---------------------------------------------------------------------------------------------- */

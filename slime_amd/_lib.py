@@ -92,6 +92,10 @@ _SIGNATURES = {
     "slime_tile_normalize": (c_int, [c_void_p, c_int, c_int, c_int, _P(c_float), _P(c_float), c_void_p, c_int, c_void_p]),
     "slime_router_scores": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "slime_router_select": (c_int, [c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "slime_router_batched_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "slime_router_scores_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                            c_void_p, c_void_p]),
+    "slime_router_select_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "slime_vit_workspace_bytes": (c_size_t, [_P(VitDesc), c_int]),
     "slime_vit_forward": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),

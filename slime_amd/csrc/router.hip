@@ -12,11 +12,15 @@
 #include "common.h"
 
 // w[l] = mask[l] / max(|text[l]|, eps)   (one wave per text token)
+// (all kernels below: blockIdx.y = image of the batch; per-image strides are passed in elements)
 __global__ void __launch_bounds__(256) router_text_weight_kernel(const float* text, const unsigned char* mask, float* w,
-                                                                 int L, int H, float eps, int have_mask, float no_mask_w) {
+                                                                 int L, int H, float eps, int have_mask, float no_mask_w, int w_stride) {
     const int lane = threadIdx.x & 63;
     const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (l >= L) return;
+    text += (size_t)blockIdx.y * L * H;
+    if (have_mask) mask += (size_t)blockIdx.y * L;
+    w += (size_t)blockIdx.y * w_stride;
     const float* r = text + (size_t)l * H;
     float s = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
@@ -31,18 +35,29 @@ __global__ void __launch_bounds__(256) router_text_weight_kernel(const float* te
 }
 
 // u[h] = sum_l w[l] * text[l][h]   (thread per column, coalesced over h; fixed summation order)
-__global__ void __launch_bounds__(256) router_text_dir_kernel(const float* text, const float* w, float* u, int L, int H) {
+__global__ void __launch_bounds__(256) router_text_dir_kernel(const float* text, const float* w, float* u, int L, int H, int w_stride) {
     const int h = blockIdx.x * 256 + threadIdx.x;
     if (h >= H) return;
+    text += (size_t)blockIdx.y * L * H;
+    w += (size_t)blockIdx.y * w_stride;
+    u += (size_t)blockIdx.y * w_stride;
     float s = 0.f;
     for (int l = 0; l < L; ++l) s += w[l] * text[(size_t)l * H + h];
     u[h] = s;
 }
 
 // scores[t] = (img[t] . u) / max(|img[t]|, eps)
-__global__ void __launch_bounds__(256) router_scores_kernel(const float* img, const float* u, float* scores, int T, int H, float eps) {
+// image b: rows row_off[b] .. row_off[b] + n_rows[b] - 1 of img (NULL tables: one image of T rows at row 0)
+__global__ void __launch_bounds__(256) router_scores_kernel(const float* img, const float* u, float* scores, int T, int H, float eps,
+                                                            const long long* row_off, const int* n_rows, int u_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n_rows) {
+        if (t >= n_rows[blockIdx.y]) return;
+        img += (size_t)row_off[blockIdx.y] * H;
+        u += (size_t)blockIdx.y * u_stride;
+        scores += (size_t)blockIdx.y * T;
+    }
     if (t >= T) return;
     const float* r = img + (size_t)t * H;
     float d = 0.f, s = 0.f;
@@ -58,7 +73,13 @@ __global__ void __launch_bounds__(256) router_scores_kernel(const float* img, co
 
 #define ROUTER_MAX_T 4096
 __global__ void __launch_bounds__(1024) router_select_kernel(const float* scores, int T, float temp, float topp,
-                                                             int* keep_idx, int* keep_count, float* probs_out) {
+                                                             int* keep_idx, int* keep_count, float* probs_out, const int* n_rows) {
+    if (n_rows) {                                     // batched: image blockIdx.x, padded [B, T] layouts
+        scores += (size_t)blockIdx.x * T; keep_idx += (size_t)blockIdx.x * T; keep_count += blockIdx.x;
+        if (probs_out) probs_out += (size_t)blockIdx.x * T;
+        T = n_rows[blockIdx.x];
+        if (T <= 0) { if (threadIdx.x == 0) *keep_count = 0; return; }
+    }
     __shared__ float key[ROUTER_MAX_T];
     __shared__ int idx[ROUTER_MAX_T];
     __shared__ float red[32];
@@ -146,9 +167,9 @@ extern "C" int slime_router_scores(const float* img, int T, const float* text, i
     float* w = ws;
     float* u = ws + ((L + 3) / 4 * 4);
     hipLaunchKernelGGL(router_text_weight_kernel, dim3((L + 3) / 4), dim3(256), 0, s, text, mask, w, L, H, 1e-8f,
-                       mask ? 1 : 0, 1.0f / (float)L);
-    hipLaunchKernelGGL(router_text_dir_kernel, dim3((H + 255) / 256), dim3(256), 0, s, text, w, u, L, H);
-    hipLaunchKernelGGL(router_scores_kernel, dim3((T + 3) / 4), dim3(256), 0, s, img, u, scores, T, H, 1e-8f);
+                       mask ? 1 : 0, 1.0f / (float)L, 0);
+    hipLaunchKernelGGL(router_text_dir_kernel, dim3((H + 255) / 256), dim3(256), 0, s, text, w, u, L, H, 0);
+    hipLaunchKernelGGL(router_scores_kernel, dim3((T + 3) / 4), dim3(256), 0, s, img, u, scores, T, H, 1e-8f, nullptr, nullptr, 0);
     SLIME_CHECK_LAUNCH("router_scores");
     return SLIME_OK;
 }
@@ -159,7 +180,43 @@ extern "C" int slime_router_select(const float* scores, int T, float temp, float
     SLIME_REQUIRE(T > 0 && T <= ROUTER_MAX_T, "router_select: T=%d outside 1..%d", T, ROUTER_MAX_T);
     SLIME_REQUIRE(temp > 0.f, "router_select: temperature must be positive");
     hipLaunchKernelGGL(router_select_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, scores, T, temp, topp,
-                       keep_idx, keep_count, probs_out);
+                       keep_idx, keep_count, probs_out, nullptr);
     SLIME_CHECK_LAUNCH("router_select");
+    return SLIME_OK;
+}
+
+// ---- the B images of a step in one launch sequence (same arithmetic per image; results identical to B single calls) ----
+extern "C" size_t slime_router_batched_workspace_floats(int B, int L, int H) {
+    if (B <= 0 || L <= 0 || H <= 0) return 0;
+    const size_t per = (size_t)((L + 3) / 4 * 4) > (size_t)H ? (size_t)((L + 3) / 4 * 4) : (size_t)H;
+    return 2 * per * B;
+}
+
+extern "C" int slime_router_scores_batched(const float* img, const long long* row_off, const int* n_rows, int B, int T_max,
+                                           const float* text, int L, const unsigned char* mask, int H, float* scores,
+                                           float* ws, void* stream) {
+    SLIME_REQUIRE(img && row_off && n_rows && text && scores && ws && B > 0 && B <= 65535 && T_max > 0 && L > 0 && H % 4 == 0,
+                  "router_scores_batched: bad input");
+    hipStream_t s = (hipStream_t)stream;
+    const int per = (L + 3) / 4 * 4 > H ? (L + 3) / 4 * 4 : H;     // one stride for the w [L] and u [H] tables of an image
+    float* w = ws;
+    float* u = ws + (size_t)per * B;
+    hipLaunchKernelGGL(router_text_weight_kernel, dim3((L + 3) / 4, B), dim3(256), 0, s, text, mask, w, L, H, 1e-8f,
+                       mask ? 1 : 0, 1.0f / (float)L, per);
+    hipLaunchKernelGGL(router_text_dir_kernel, dim3((H + 255) / 256, B), dim3(256), 0, s, text, w, u, L, H, per);
+    hipLaunchKernelGGL(router_scores_kernel, dim3((T_max + 3) / 4, B), dim3(256), 0, s, img, u, scores, T_max, H, 1e-8f, row_off,
+                       n_rows, per);
+    SLIME_CHECK_LAUNCH("router_scores_batched");
+    return SLIME_OK;
+}
+
+extern "C" int slime_router_select_batched(const float* scores, const int* n_rows, int B, int T_max, float temp, float topp,
+                                           int* keep_idx, int* keep_count, void* stream) {
+    SLIME_REQUIRE(scores && n_rows && keep_idx && keep_count && B > 0, "router_select_batched: bad input");
+    SLIME_REQUIRE(T_max > 0 && T_max <= ROUTER_MAX_T, "router_select_batched: T_max=%d outside 1..%d", T_max, ROUTER_MAX_T);
+    SLIME_REQUIRE(temp > 0.f, "router_select_batched: temperature must be positive");
+    hipLaunchKernelGGL(router_select_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, T_max, temp, topp, keep_idx,
+                       keep_count, (float*)nullptr, n_rows);
+    SLIME_CHECK_LAUNCH("router_select_batched");
     return SLIME_OK;
 }

@@ -229,9 +229,13 @@ class SlimeMetaForCausalLM(ABC):
                 tokens = _fused_adapter(model, images, layout, torch.float32)        # [B, 576 + n*g*g, H] fp32
                 P = tower.num_patches
                 sep32 = sep.to(device=tokens.device, dtype=torch.float32).unsqueeze(0)
+                rows = tokens.shape[1]
+                # router: all B images in one launch pair, one D2H for the B kept counts (the reference syncs per image)
+                keeps = model.sampler.select_batched(tokens.view(B * rows, -1), [i * rows + P for i in range(B)], [rows - P] * B,
+                                                     text_emb, text_mask)
                 outs = []
                 for i in range(B):
-                    routed = model.sampler(tokens[i, P:], text_embedding=text_emb[i], attn_mask=text_mask[i])
+                    routed = tokens[i, P:].index_select(0, keeps[i])
                     outs.append(torch.cat([tokens[i, :P], sep32, routed], dim=0).to(out_dtype).unsqueeze(0))
                 return outs, split_sizes
             feats = tower(images, out_dtype=torch.float32)                      # [sum(1+n_i), 576, D], one batch
@@ -244,35 +248,47 @@ class SlimeMetaForCausalLM(ABC):
                 comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)    # [sum n_i,144,D]
                 loc = _project_local(model.mm_projector, comp)                                   # [sum n_i,144,H]
             g = model.sampler.grid_size
-            outs = []
+            merged_list = []
             lstart = 0
             for i in range(B):
+                if loc is None:
+                    break
                 n_i = split_sizes[i] - 1
+                li = loc[lstart:lstart + n_i]
+                lstart += n_i
+                if images_mask is not None and images_mask[0].size(0) - 1 == li.size(0):
+                    li = li[torch.nonzero(images_mask[i][1:]).squeeze(1)]    # padded crops (train.py:903-926)
+                H = li.shape[-1]
+                merged = torch.empty((li.shape[0] * g * g, H), dtype=torch.float32, device=dev)
+                if li.shape[0] > 0:
+                    if merge_type == "spatial":
+                        nw, nh = get_anyres_image_grid_shape(image_sizes[i], cfg.image_grid_pinpoints, tower.config.image_size)
+                        if nw * nh != li.shape[0]:
+                            raise ValueError(f"image {i}: grid {nw}x{nh} does not match {li.shape[0]} local crops")
+                        ops.merge_rows(li.contiguous(), merged, 0, nw, nh, g, True)
+                    elif merge_type == "flat":
+                        ops.merge_rows(li.contiguous(), merged, 0, li.shape[0], 1, g, False)
+                    else:
+                        raise NotImplementedError(f"mm_patch_merge_type={merge_type!r}")
+                merged_list.append(merged)
+            keeps = None
+            if merged_list:
+                # one ragged concatenation -> one batched router call (one D2H for all kept counts)
+                cat = torch.cat(merged_list, 0)
+                offs, o = [], 0
+                for m_ in merged_list:
+                    offs.append(o)
+                    o += m_.shape[0]
+                keeps = model.sampler.select_batched(cat, offs, [m_.shape[0] for m_ in merged_list], text_emb, text_mask)
+            outs = []
+            for i in range(B):
                 pieces = []
                 if glob is not None:
                     pieces.append(glob[i])
                 if loc is not None:
-                    li = loc[lstart:lstart + n_i]
-                    lstart += n_i
-                    if images_mask is not None and images_mask[0].size(0) - 1 == li.size(0):
-                        li = li[torch.nonzero(images_mask[i][1:]).squeeze(1)]    # padded crops (train.py:903-926)
-                    H = li.shape[-1]
-                    merged = torch.empty((li.shape[0] * g * g, H), dtype=torch.float32, device=dev)
-                    if li.shape[0] > 0:
-                        if merge_type == "spatial":
-                            nw, nh = get_anyres_image_grid_shape(image_sizes[i], cfg.image_grid_pinpoints,
-                                                                 tower.config.image_size)
-                            if nw * nh != li.shape[0]:
-                                raise ValueError(f"image {i}: grid {nw}x{nh} does not match {li.shape[0]} local crops")
-                            ops.merge_rows(li.contiguous(), merged, 0, nw, nh, g, True)
-                        elif merge_type == "flat":
-                            ops.merge_rows(li.contiguous(), merged, 0, li.shape[0], 1, g, False)
-                        else:
-                            raise NotImplementedError(f"mm_patch_merge_type={merge_type!r}")
-                    merged = model.sampler(merged, text_embedding=text_emb[i], attn_mask=text_mask[i])
                     if glob is not None:
                         pieces.append(sep.to(device=dev, dtype=torch.float32).unsqueeze(0))
-                    pieces.append(merged)
+                    pieces.append(merged_list[i].index_select(0, keeps[i]))
                 outs.append(torch.cat(pieces, dim=0).to(out_dtype).unsqueeze(0))
             return outs, split_sizes
 

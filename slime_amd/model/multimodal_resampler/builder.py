@@ -37,6 +37,13 @@ class TextGuidedSampler(nn.Module):
         return local_f[keep]
 
 
+    @torch.no_grad()
+    def select_batched(self, tokens, row_off, n_rows, text_embedding, attn_mask=None):
+        """Router for all images of a step at once (ops.router_topp_batched: one launch pair, one D2H): per image the kept
+        local-token indices, ascending.  Same per-image arithmetic as ``forward``."""
+        return ops.router_topp_batched(tokens, row_off, n_rows, text_embedding, attn_mask, float(self.topp), float(self.temp))
+
+
 def build_vision_sampler(config, delay_load=False, **kwargs):
     mm_resampler_type = getattr(config, "mm_resampler_type", None)
     if mm_resampler_type == "identity" or mm_resampler_type is None:

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 from dataclasses import dataclass, field
-from typing import Dict, Optional
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn.functional as F
@@ -559,6 +559,37 @@ def router_topp(local_f: torch.Tensor, text: torch.Tensor, mask: Optional[torch.
         return torch.zeros((0,), dtype=torch.long, device=local_f.device)
     keep, cnt = router_select(router_scores(local_f, text, mask), topp, temp)
     return keep[: int(cnt.item())].long()
+
+
+def router_topp_batched(tokens: torch.Tensor, row_off: Sequence[int], n_rows: Sequence[int], text: torch.Tensor,
+                        mask: Optional[torch.Tensor], topp: float, temp: float) -> List[torch.Tensor]:
+    """The router for the B images of a step in ONE launch pair and ONE D2H read (of the B kept counts).
+    ``tokens`` fp32 [rows, H] (any 2-D contiguous view of the token buffer); image b owns rows
+    ``row_off[b] .. row_off[b] + n_rows[b] - 1``; ``text`` [B, L, H], ``mask`` [B, L] or None.
+    Returns per image the kept LOCAL indices (ascending, int64, relative to row_off[b])."""
+    lib = _lib.load()
+    _require_cuda(tokens, "tokens")
+    assert tokens.dim() == 2 and tokens.dtype == torch.float32 and tokens.is_contiguous()
+    B, H = len(n_rows), tokens.shape[1]
+    dev = tokens.device
+    T_max = max(int(n) for n in n_rows) if B else 0
+    if B == 0 or T_max == 0:
+        return [torch.zeros((0,), dtype=torch.long, device=dev) for _ in range(B)]
+    txt = text.to(device=dev, dtype=torch.float32).contiguous()
+    L = txt.shape[1]
+    m = None if mask is None else mask.to(device=dev).ne(0).to(torch.uint8).contiguous()
+    off = torch.tensor([int(o) for o in row_off], dtype=torch.int64).to(dev, non_blocking=True)
+    cnt_in = torch.tensor([int(n) for n in n_rows], dtype=torch.int32).to(dev, non_blocking=True)
+    scores = torch.empty((B, T_max), dtype=torch.float32, device=dev)
+    keep = torch.empty((B, T_max), dtype=torch.int32, device=dev)
+    cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws = torch.empty((lib.slime_router_batched_workspace_floats(B, L, H) + 8,), dtype=torch.float32, device=dev)
+    _lib.check(lib.slime_router_scores_batched(tokens.data_ptr(), off.data_ptr(), cnt_in.data_ptr(), B, T_max, txt.data_ptr(), L,
+                                               _ptr(m), H, scores.data_ptr(), ws.data_ptr(), _stream()), "slime_router_scores_batched")
+    _lib.check(lib.slime_router_select_batched(scores.data_ptr(), cnt_in.data_ptr(), B, T_max, float(temp), float(topp),
+                                               keep.data_ptr(), cnt.data_ptr(), _stream()), "slime_router_select_batched")
+    counts = cnt.cpu().tolist()                                   # the step's only host sync
+    return [keep[b, :counts[b]].long() for b in range(B)]
 
 
 # ------------------------------------------------------------------------------------------------

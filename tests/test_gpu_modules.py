@@ -370,3 +370,57 @@ def test_stacked_local_crops_of_576_take_the_mlp(dev):
     assert torch.equal(out[:5], part)
     with pytest.raises(ValueError, match="GatedBlock expects"):
         proj(comp)                                             # the shape test itself is the reference's (builder.py:180)
+
+
+def test_router_matches_reference_goldens(dev):
+    """the kept count and the first kept rows of the REFERENCE's own router run (tiny_stages.npz:
+    n*_router_rows / n*_router_first / n*_router_scores) are reproduced exactly by the HIP router when it is fed the same
+    merged tokens (the oracle's, which equal the reference's to 2e-5): 273/288, 545/576, 817/864 here."""
+    import os
+    from conftest import GOLDEN
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    g = np.load(os.path.join(GOLDEN, "tiny_stages.npz"))
+    tsd = W.strip_tower_prefix(W.make_tower_state_dict(W.TINY, seed=11))
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=12)
+    for n_local, size in ((2, (336, 336)), (4, (672, 672)), (6, (1344, 1344))):
+        k = f"n{n_local}_"
+        px = W.synthetic_pixels(1 + n_local, seed=20 + n_local)
+        merged = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px, size)["merged"]
+        text = torch.randn(9, W.ADAPTER_TINY.hidden_size, generator=torch.Generator().manual_seed(300 + n_local))
+        mask = torch.tensor([1, 1, 1, 1, 1, 1, 0, 0, 1], dtype=torch.bool)
+        sc = ops.router_scores(merged.to(dev), text.to(dev), mask.to(dev))
+        assert rel_l2(sc.cpu(), g[k + "router_scores"]) < 2e-5
+        keep = ops.router_topp(merged.to(dev), text.to(dev), mask.to(dev), 0.95, 1.0).cpu()
+        assert keep.numel() == int(g[k + "router_rows"][0])
+        assert rel_l2(merged[keep[:4]], g[k + "router_first"]) < 2e-5
+        assert torch.equal(keep, O.router_select(torch.from_numpy(g[k + "router_scores"]), 0.95, 1.0))
+
+
+def test_router_exact_on_separated_scores_and_batched_equals_single(dev):
+    """Selection is discontinuous in the scores, so exactness is demanded where it is well defined: scores separated by
+    far more than fp32 rounding -> the kept SET equals the oracle's for every (top-p, temperature); and the batched
+    launch (fused strided layout and ragged concatenation, with an empty image) equals per-image calls bit for bit."""
+    from slime_amd import ops
+    from oracle import slime_oracle as O
+    gen = torch.Generator().manual_seed(17)
+    for T in (37, 288, 1008, 4096):
+        sc = (torch.linspace(-4, 4, T)[torch.randperm(T, generator=gen)]).contiguous()
+        for topp, temp in ((0.95, 1.0), (0.5, 0.3), (0.999, 2.0), (1.0, 1.0), (1e-4, 1.0)):
+            keep, cnt = ops.router_select(sc.to(dev), topp, temp)
+            got = keep[: int(cnt.item())].cpu().long()
+            assert torch.equal(got, O.router_select(sc, topp, temp)), (T, topp, temp)
+    B, P, T, H, L = 3, 5, 288, 256, 9
+    tokens = torch.randn(B, P + T, H, generator=gen).to(dev)
+    text = torch.randn(B, L, H, generator=gen).to(dev)
+    mask = (torch.rand(B, L, generator=gen) > 0.3).to(dev)
+    single = [ops.router_topp(tokens[i, P:].contiguous(), text[i], mask[i], 0.95, 1.0) for i in range(B)]
+    fused = ops.router_topp_batched(tokens.view(B * (P + T), H), [i * (P + T) + P for i in range(B)], [T] * B, text, mask, 0.95, 1.0)
+    for a, b in zip(single, fused):
+        assert torch.equal(a, b)
+    lens = [T, 0, 144]
+    cat = torch.cat([tokens[0, P:], tokens[2, P:P + 144]], 0).contiguous()
+    ragged = ops.router_topp_batched(cat, [0, T, T], lens, text, None, 0.9, 0.7)
+    assert ragged[1].numel() == 0
+    assert torch.equal(ragged[0], ops.router_topp(tokens[0, P:].contiguous(), text[0], None, 0.9, 0.7))
+    assert torch.equal(ragged[2], ops.router_topp(tokens[2, P:P + 144].contiguous(), text[2], None, 0.9, 0.7))
