@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
 """Contract benchmark: image-crops/sec of the SliME visual hot path (ViT + projector) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One STEP = one pass of the hot path over one batch of synthetic input of BASELINE.json configs[1]:
-8 images x (1 global + 4 local) 336x336 crops = 40 crops per GPU (weak scaling: the global batch is
-8*N images), bf16 MFMA operands, inputs already resident in HBM:
+Default (= what the driver runs) is BASELINE.json configs[1] ("config 2"): one STEP = one pass of the hot path over
+8 images x (1 global + 4 local) 336x336 crops = 40 crops per GPU (weak scaling: the global batch is 8*N images), bf16 MFMA
+operands, inputs already resident in HBM:
 
-    CLIP-ViT-L/14-336 tower over all crops of the rank (23 live layers)  ->  [N>1] RCCL all-gather of the
-    bf16 tower features of all ranks  ->  gated global adapter (576 tokens/image), post_qformer local
-    compression (144 tokens/crop) + MLP projector, spatial merge into LLM-ready token rows.
+    CLIP-ViT-L/14-336 tower over all crops of the rank (23 live layers)  ->  [N>1] RCCL all-gather of the bf16 tower
+    features  ->  gated global adapter (576 tokens/image), post_qformer local compression (144 tokens/crop) + MLP
+    projector, spatial merge into LLM-ready token rows.
+
+--config 3  BASELINE configs[2]: 4 images x (1 global + 16 local) = 68 crops, STRONG scaling: the crop list is block
+            partitioned over the ranks (ceil(68/N) per rank, zero-padded: slime_amd.dist.sharded_tower), features are
+            all-gathered (chunked, under the tower), the adapter (4 x 4 spatial merge) runs on the image-owning rank.
+--config 4  BASELINE configs[3], one GPU: config 2's encode + the visual-token splice into 8 text sequences + the
+            attention sub-layer of all 32 Llama-3-8B layers over the spliced sequences (slime_llama_attn_forward:
+            q/k/v GEMM, RoPE, causal GQA attention, o_proj); reports the prefill-attention kernel's own roofline.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the dominant kernel (the fused-epilogue MFMA GEMM; the heaviest launch shape of the
-                 step), algorithmic FLOPs / live HIP-event duration, against the dense bf16 MFMA peak;
-  cpu_baseline : the CPU oracle (oracle/slime_oracle.py, a restatement validated against the
-                 reference) timed on this box's host cores on a bounded sample (N == 1 only).
+  roofline     : the dominant kernel of the step, algorithmic FLOPs / live HIP-event duration, against the dense bf16 MFMA peak;
+  cpu_baseline : the CPU oracle (oracle/slime_oracle.py, a restatement validated against the reference) timed on this box's
+                 host cores on a bounded sample (N == 1, config 2 only).
 """
 from __future__ import annotations
 
@@ -31,13 +37,17 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-IMAGES_PER_GPU = 8
-LOCAL_CROPS = 4                        # 672x672 input -> 2x2 local grid
-CROPS_PER_IMAGE = 1 + LOCAL_CROPS
 GF_VIT_PER_CROP = 366.034              # live ViT path, 23 layers, S = 577
 GF_GLOBAL_PER_IMAGE = 54.512           # gated adapter on the global view
 GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PMC_FILE = "r02_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
+
+CONFIGS = {                            # images per step, local crops per image, local grid
+    2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
+    3: dict(images=4, local=16, grid=(4, 4), scaling="strong"),
+    4: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
+}
 
 
 def parse():
@@ -45,34 +55,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run gather + adapter of a step on the tower's stream instead of a second stream")
+    ap.add_argument("--gather", choices=["chunked", "oneshot", "compressed"], default="chunked",
+                    help="config 3 exchange: chunked async all-gather under the tower (default), one blocking all-gather, or "
+                         "post_qformer on the shard + gather of compressed local crops")
     return ap.parse_args()
 
 
-def event_time_ms(fn, iters=10, warm=2):
-    """Average duration of ``fn`` (one kernel launch) with HIP events on the launching stream."""
-    for _ in range(warm):
-        fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
-
-
-# kernel id in the tower driver (include/slime_hip.h: slime_probe) -> (label, rocprof kernel name, N, K)
-PROBE_KERNELS = {
-    1: ("qkv_proj", "gemm_w4_kernel<BF16, 0, 0, 6, 0>", 3072, 1024),
-    3: ("out_proj+residual", "gemm_pp_kernel<BF16, 4, 0, 0, 4>", 1024, 1024),
-    5: ("fc1+quick_gelu", "gemm_w4_kernel<BF16, 1, 0, 8, 0>", 4096, 1024),
-    6: ("fc2+residual", "gemm_pp_kernel<BF16, 4, 1, 0, 4>", 1024, 4096),
-    2: ("attention", "attn64_kernel<BF16>", 0, 0),
-}
+# kernel id in the tower driver (include/slime_hip.h: slime_probe) -> (label, N, K); attention has N = K = 0
+PROBE_KERNELS = {1: ("qkv_proj", 3072, 1024), 3: ("out_proj+residual", 1024, 1024), 5: ("fc1+quick_gelu", 4096, 1024),
+                 6: ("fc2+residual", 1024, 4096), 2: ("attention", 0, 0), 0: ("layernorm1", -1, 0), 4: ("layernorm2", -1, 0)}
 
 
 def kernel_roofline(vision_model, pixels_half, reps=4, layer=11):
@@ -86,8 +81,11 @@ def kernel_roofline(vision_model, pixels_half, reps=4, layer=11):
     crops = pixels_half.shape[0]
     M = crops * 577
     pt = vision_model.packed(-2, 0)
+    names = ops.tower_kernel_names(pt, crops)
     per = {}
-    for kid, (label, name, N, K) in PROBE_KERNELS.items():
+    for kid, (label, N, K) in PROBE_KERNELS.items():
+        if kid not in names:
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); e1.record()                           # force creation of the HIP events
         pt.probe = (layer, kid, e0, e1)
@@ -99,18 +97,25 @@ def kernel_roofline(vision_model, pixels_half, reps=4, layer=11):
             ms.append(e0.elapsed_time(e1))
         pt.probe = None
         avg = sum(ms) / len(ms)
-        fl = 4.0 * crops * 16 * 577 * 577 * 64 if kid == 2 else 2.0 * M * N * K
-        per[kid] = {"label": label, "rocprof_name": name, "ms": round(avg, 4), "min_ms": round(min(ms), 4),
+        if kid == 2:
+            fl = 4.0 * crops * 16 * 577 * 577 * 64
+        elif N < 0:
+            fl = 0.0
+        else:
+            fl = 2.0 * M * N * K
+        per[kid] = {"label": label, "rocprof_name": names[kid], "ms": round(avg, 4), "min_ms": round(min(ms), 4),
                     "tflops": round(fl / avg / 1e9, 1), "gflop_per_launch": round(fl / 1e9, 2), "M": M, "N": N, "K": K}
-    dom = max((k for k in per if k != 2), key=lambda k: per[k]["ms"])
+        if N < 0:
+            per[kid]["gb_per_s"] = round(M * 1024 * 6 / avg / 1e6, 1)          # fp32 in + 16-bit out
+    dom = max((k for k in per if per[k]["N"] > 0), key=lambda k: per[k]["ms"])
     return dom, per
 
 
-def cpu_baseline(tower_sd, adapter_sd):
+def cpu_baseline(tower_sd, adapter_sd, crops_per_image):
     """Oracle (CPU restatement of the reference) on one 1+4 image; a reported baseline, not a target."""
     from oracle import slime_oracle as O
     from slime_amd import weights as W
-    px = W.synthetic_pixels(CROPS_PER_IMAGE, seed=7)
+    px = W.synthetic_pixels(crops_per_image, seed=7)
     tsd = W.strip_tower_prefix(tower_sd)
     best = None
     t_all = time.perf_counter()
@@ -121,12 +126,31 @@ def cpu_baseline(tower_sd, adapter_sd):
         best = dt if best is None else min(best, dt)
         if time.perf_counter() - t_all > 20:
             break
-    return {"value": round(CROPS_PER_IMAGE / best, 3), "unit": "crops/s", "cores": torch.get_num_threads(),
+    return {"value": round(crops_per_image / best, 3), "unit": "crops/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"1 image x (1+4) crops, fp32 torch CPU oracle (tower 23 layers + adapter + merge), best of <=2 runs, {best:.2f} s"}
+
+
+def pmc_traffic(rocprof_name):
+    """HBM bytes per launch of a kernel from the COMMITTED PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, profiles/README.md).
+    It is a profile of this kernel at this shape, not a measurement of this run (PMC counters need rocprofv3 around the process):
+    the bench line says so in `traffic_source`; null if the kernel is not in the committed summary."""
+    pmc = os.path.join(ROOT, "profiles", PMC_FILE)
+    if not os.path.isfile(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
+    try:
+        rec = json.load(open(pmc)).get(rocprof_name, {})
+        if "hbm_read_bytes_corrected" in rec and "hbm_write_bytes" in rec:
+            return int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"]), "profiles/" + os.path.basename(pmc)
+    except Exception:
+        pass
+    return None, None
 
 
 def main():
     args = parse()
+    C = CONFIGS[args.config]
+    IMAGES, LOCAL, (NW, NH) = C["images"], C["local"], C["grid"]
+    CPI = 1 + LOCAL
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +158,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.config == 4 and world > 1:
+        raise SystemExit("--config 4 is the single-GPU prefill configuration (BASELINE configs[3])")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     import torch.distributed as dist
@@ -161,7 +187,7 @@ def main():
 
     from slime_amd import weights as W, ops
     from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
-    from slime_amd.dist import sharded_tower_gather
+    from slime_amd import dist as D
 
     dt = torch.bfloat16
     tower_sd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)
@@ -172,44 +198,91 @@ def main():
     enc.get_vision_tower().vision_tower.to(dt)          # bf16 tower (training dtype of the reference, BASELINE cfg)
     model = enc.get_model()
     tower = enc.get_vision_tower()
-
-    n_local = IMAGES_PER_GPU * CROPS_PER_IMAGE
-    pixels = W.synthetic_pixels(n_local, seed=100 + rank).to(dev).to(dt)     # resident in HBM before timing
-    split_sizes = [CROPS_PER_IMAGE] * IMAGES_PER_GPU
-    image_sizes = [(672, 672)] * IMAGES_PER_GPU
     g = model.sampler.grid_size
-    rows_per_image = 576 + LOCAL_CROPS * g * g
     pg = model.mm_projector.packed(dt)
     post = model.sampler.post_qformer.packed(576, dt)
+    n_step = IMAGES * CPI                                # crops per step per GPU (config 2/4) or in total (config 3)
+    strong = C["scaling"] == "strong"
+    extra_cfg = {}
 
     # Steps are independent batches, so the tail of step i (all-gather + adapter: small, partly under-filled launches,
     # and for N > 1 an xGMI transfer) is enqueued on its own stream and runs under the tower of step i+1; the timed
     # region ends with a device-wide synchronize, i.e. all K steps are complete inside it.
     tail_stream = None if args.no_pipeline else torch.cuda.Stream(device=dev)
 
-    def tail(feats):
-        if collective:
-            allf = sharded_tower_gather(feats, world)                        # [40*G,576,1024] on every rank
-            feats = allf[rank * n_local:(rank + 1) * n_local]
-        # GatedBlock on the global crops + post_qformer / projection MLP / spatial merge on the local crops: one C-ABI
-        # call (slime_adapter_forward), tokens [images, 576 + 4*144, 4096] bf16
-        return ops.adapter_forward(pg, post, feats, IMAGES_PER_GPU, LOCAL_CROPS, 2, 2, True, -1, dt)
+    if not strong:
+        pixels = W.synthetic_pixels(n_step, seed=100 + rank).to(dev).to(dt)     # resident in HBM before timing
+
+        def tail(feats):
+            if collective:
+                # weak scaling: every rank owns whole images, so the adapter needs no remote features.  north_star asks for the
+                # all-gather that reassembles the visual tokens on every rank (the LLM consumes all of them); it is issued
+                # asynchronously and overlaps the adapter, which works on the rank's own block.
+                allf = torch.empty((world * feats.shape[0],) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
+                work = dist.all_gather_into_tensor(allf, feats.contiguous(), async_op=True)
+            out = ops.adapter_forward(pg, post, feats, IMAGES, LOCAL, NW, NH, True, -1, dt)
+            if collective:
+                work.wait()
+            return out
+
+        def produce():
+            return tower(pixels)                                                 # [40,576,1024] bf16
+        extra_cfg["gather"] = "async all-gather of the rank's bf16 tower features, overlapping the adapter (overhead-only in weak scaling: each rank's adapter reads its own block)" if collective else "none"
+    else:
+        # strong scaling (config 3): identical crop list on every rank; rank r encodes its block, the exchange reassembles
+        # what the adapter needs, the adapter runs for the images this rank owns
+        pixels = W.synthetic_pixels(n_step, seed=100).to(dev).to(dt)
+        vm = tower.vision_tower
+        my_images = D.image_shard(IMAGES, world, rank)
+        lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
+
+        def tower_fn(x):
+            return vm.encode(x, -2, False, dt)
+
+        def compress_fn(x):
+            return ops.resampler_forward(post, x.float(), want_t=True)[1]
+
+        def produce():
+            if args.gather == "compressed":
+                return D.sharded_tower_compressed(tower_fn, compress_fn, pixels, CPI, (576, 1024), g * g, dt)
+            return D.sharded_tower(tower_fn, pixels, (576, 1024), dt, chunk=3 if args.gather == "chunked" else 0)
+
+        def tail(feats):
+            if hi_i == lo_i:
+                return None
+            if args.gather == "compressed":
+                glob, comp = feats
+                return ops.adapter_forward_precompressed(pg, glob[lo_i:hi_i], comp[lo_i * LOCAL:hi_i * LOCAL], hi_i - lo_i, LOCAL,
+                                                         NW, NH, True, -1, dt)
+            return ops.adapter_forward(pg, post, feats[lo_i * CPI:hi_i * CPI], hi_i - lo_i, LOCAL, NW, NH, True, -1, dt)
+        full_b, comp_b = D.gather_bytes(n_step, CPI, world)
+        extra_cfg.update({"gather": args.gather, "gather_bytes_per_rank": comp_b if args.gather == "compressed" else full_b,
+                          "crops_per_rank_padded": -(-n_step // world), "images_owned_by_rank0": len(my_images)})
+
+    # config 4: splice + 32 Llama-3-8B attention sub-layers over the spliced sequences
+    prefill = None
+    if args.config == 4:
+        prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g)
 
     def step():
-        feats = tower(pixels)                                                # [40,576,1024] bf16
+        feats = produce()
         if tail_stream is None:
-            return tail(feats)
+            out = tail(feats)
+            return prefill(out) if prefill else out
         ready = torch.cuda.Event()
         ready.record()
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ready)
-            feats.record_stream(tail_stream)
-            return tail(feats)
+            for t in (feats if isinstance(feats, tuple) else (feats,)):
+                t.record_stream(tail_stream)
+            out = tail(feats)
+            return prefill(out) if prefill else out
 
     def barrier():
         if collective:
             dist.barrier()
 
+    out = None
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -221,55 +294,61 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    assert torch.isfinite(out.float()).all()
+    if out is not None:
+        assert torch.isfinite(out.float()).all()
     if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        crops_total = n_local * world * args.steps
+        crops_total = n_step * (1 if strong else world) * args.steps
         value = crops_total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
-        step_gf = n_local * GF_VIT_PER_CROP + IMAGES_PER_GPU * GF_GLOBAL_PER_IMAGE + IMAGES_PER_GPU * LOCAL_CROPS * GF_LOCAL_PER_CROP
-        path_tflops = step_gf * world / (elapsed / args.steps) / 1e3
+        step_gf = n_step * GF_VIT_PER_CROP + IMAGES * GF_GLOBAL_PER_IMAGE + IMAGES * LOCAL * GF_LOCAL_PER_CROP
+        if prefill:
+            step_gf += prefill.gflop
+        path_tflops = step_gf * (1 if strong else world) / (elapsed / args.steps) / 1e3
         halves = 2 if tower.vision_tower.two_streams else 1
-        dom, per = kernel_roofline(tower.vision_tower, pixels[: n_local // halves].contiguous())
-        traffic = None
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-        # profiles/README.md); null if that kernel is not in the committed summary
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
-        if os.path.isfile(pmc):
-            try:
-                rec = json.load(open(pmc)).get(per[dom]["rocprof_name"], {})
-                if "hbm_read_bytes_corrected" in rec and "hbm_write_bytes" in rec:
-                    traffic = int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"])
-            except Exception:
-                traffic = None
+        per_rank = -(-n_step // world) if strong else n_step
+        n_half = per_rank // halves if per_rank >= 16 else per_rank
+        dom, per = kernel_roofline(tower.vision_tower, pixels[:n_half].contiguous())
+        roof_kernel = per[dom]
+        if prefill:
+            pk = prefill.kernel_times()
+            per.update(pk)
+            roof_kernel = pk["prefill_attention"]
+        traffic, traffic_src = pmc_traffic(roof_kernel["rocprof_name"])
+        workload = {2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
+                    3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
+                    4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers"}[args.config]
         res = {
-            "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid",
+            "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid" if args.config != 3 else "image-crops/sec (ViT+projector) at 336px, 1+16 grid",
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), "
-                                   "tower + gated adapter + post_qformer + MLP projector + spatial merge",
-                       "crops_per_gpu": n_local, "images_per_gpu": IMAGES_PER_GPU, "grid": "1+4",
+            "config": {"workload": workload, "baseline_config": args.config,
+                       "crops_per_gpu": per_rank, "images_per_step": IMAGES * (1 if strong else world), "grid": f"1+{LOCAL}",
                        "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),
                        "tower_streams": halves,
-                       "step_pipelining": "none" if tail_stream is None else "gather+adapter of step i on a second stream, under the tower of step i+1"},
+                       "step_pipelining": "none" if tail_stream is None else "gather+adapter of step i on a second stream, under the tower of step i+1",
+                       **extra_cfg},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
-                          "gflop_per_step_per_gpu": round(step_gf, 1)},
+                          "gflop_per_step": round(step_gf, 1)},
             "roofline": {"bound": "mfma",
-                         "kernel": f"{per[dom]['rocprof_name']} ({per[dom]['label']}, M={per[dom]['M']} N={per[dom]['N']} K={per[dom]['K']})",
-                         "achieved": per[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(per[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "launch_ms": per[dom]["ms"], "gflop_per_launch": per[dom]["gflop_per_launch"],
+                         "kernel": f"{roof_kernel['rocprof_name']} ({roof_kernel['label']}, M={roof_kernel['M']} N={roof_kernel['N']} K={roof_kernel['K']})",
+                         "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(roof_kernel["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "launch_ms": roof_kernel["ms"], "gflop_per_launch": roof_kernel["gflop_per_launch"],
                          "method": "HIP events recorded by the tower driver (slime_vit_forward_ex probe) around the kernel of layer 11 on its "
-                                   "launching stream, tower pass over one half batch (the step's launch shape), other stream idle; mean of 4",
-                         "kernels": {v["label"]: {k: v[k] for k in ("rocprof_name", "ms", "min_ms", "tflops")} for v in per.values()}},
+                                   "launching stream, tower pass over one half batch (the step's launch shape), other stream idle; mean of 4"
+                                   + ("; prefill kernels: HIP events around single launches at the step's shapes" if prefill else ""),
+                         "kernels": {v["label"]: {k: v[k] for k in ("rocprof_name", "ms", "min_ms", "tflops") if k in v} for v in per.values()}},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd)
+        if prefill:
+            res["config"].update(prefill.describe())
+        if world == 1 and args.config == 2 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(tower_sd, adapter_sd, CPI)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)
@@ -277,6 +356,74 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def build_prefill(enc, dev, dt, images, visual_rows, text_tokens=64, layers=32):
+    """Config 4's second half: embed table + 32 Llama-3-8B attention sub-layers (random init), splice plan for `images`
+    sequences of [text/2, <image>, text/2]; returns a callable (visual tokens [B, rows, 4096] bf16) -> hidden states."""
+    import numpy as np
+    from slime_amd import ops
+    from slime_amd.model.llava_arch import splice_plan
+    from slime_amd.constants import IMAGE_TOKEN_INDEX
+    D, HQ, HKV = 4096, 32, 8
+    g = torch.Generator().manual_seed(99)
+    table = (torch.randn(32000, D, generator=g) * 0.02).to(dt).to(dev)
+    ids = torch.randint(3, 32000, (images, text_tokens + 1), generator=g)
+    ids[:, text_tokens // 2] = IMAGE_TOKEN_INDEX
+    src, _, mask, pos = splice_plan(ids.numpy(), None, None, [visual_rows] * images)
+    S = src.shape[1]
+    src_d = torch.from_numpy(src).reshape(-1).to(dev)
+    pos_d = torch.from_numpy(pos).to(dev)
+    packs = []
+    for _ in range(layers):
+        w = [torch.randn(n, k, generator=g, dtype=torch.float32) * (k ** -0.5) for n, k in ((HQ * 128, D), (HKV * 128, D), (HKV * 128, D), (D, HQ * 128))]
+        packs.append(ops.pack_llama_attention(w[0], w[1], w[2], w[3], HQ, HKV, dt, dev, 500000.0))
+    M = images * S
+    gf_layer = (2.0 * M * (HQ + 2 * HKV) * 128 * D + 2.0 * M * D * HQ * 128 + 4.0 * images * HQ * (S * (S + 1) / 2) * 128) / 1e9
+
+    def run(tokens):
+        feats = tokens.reshape(-1, tokens.shape[-1])
+        h = ops.splice_rows(table, feats, src_d, dt).view(images, S, D)
+        for p in packs:
+            h = h + ops.llama_attention_forward(p, h, pos_d, None, dt)         # residual add in torch; attention sub-layer in HIP
+        return h
+
+    def kernel_times():
+        lib, st = ops._lib.load(), torch.cuda.current_stream().cuda_stream
+        p = packs[0]
+        N = (HQ + 2 * HKV) * 128
+        qkv = (torch.randn(images, S, N, device=dev) * 0.3).to(dt)
+        o = torch.empty((images, S, HQ * 128), dtype=dt, device=dev)
+
+        def attn():
+            ops._lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N,
+                                                      qkv.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                                      images, HQ, HKV, 128, S, None, None, ops.dtype_code(dt), st))
+        hid = (torch.randn(M, D, device=dev) * 0.3).to(dt)
+        out = {}
+        for label, name, fn, fl, n_, k_ in (
+                ("prefill_attention", "prefill_attn_kernel<BF16>", attn, 4.0 * images * HQ * (S * (S + 1) / 2) * 128, 0, 0),
+                ("llama_qkv_proj", "gemm (q|k|v fused)", lambda: ops.gemm(hid, p.tensors["w_qkv"], None, ops._lib.EPI_BIAS_T), 2.0 * M * N * D, N, D)):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            out[label] = {"label": label, "rocprof_name": name, "ms": round(ms, 4), "min_ms": round(ms, 4),
+                          "tflops": round(fl / ms / 1e9, 1), "gflop_per_launch": round(fl / 1e9, 2), "M": M, "N": n_, "K": k_}
+        return out
+
+    run.gflop = gf_layer * layers
+    run.kernel_times = kernel_times
+    run.describe = lambda: {"prefill_sequences": images, "prefill_seq_len": S, "llama_layers": layers,
+                            "prefill_gflop_per_step": round(gf_layer * layers, 1),
+                            "prefill_note": "attention sub-layers only (q/k/v projection, RoPE, causal GQA, o_proj) + residual add; RMSNorm / MLP / lm_head are outside SURVEY section 8"}
+    return run
 
 
 if __name__ == "__main__":

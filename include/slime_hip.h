@@ -62,6 +62,9 @@ const char* slime_last_error(void);
 int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
                int M, int N, int K, int dtype, int epilogue, void* stream);
 
+/* Name (as rocprofv3 prints it) of the kernel instantiation slime_gemm launches for this shape: host-only query. */
+int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out_host, size_t out_len);
+
 /* Row-wise LayerNorm over fp32 rows (statistics in fp32, two-pass variance).
  *   y = (x - mean) * rstd * w + b            (normalize != 0)    or   y = x   (normalize == 0)
  *   out_f32[r]  = y                            if out_f32

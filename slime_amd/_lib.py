@@ -66,6 +66,7 @@ _SIGNATURES = {
     "slime_abi_version": (c_int, []),
     "slime_last_error": (C.c_char_p, []),
     "slime_gemm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, C.c_char_p, c_size_t]),
     "slime_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "slime_im2col": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

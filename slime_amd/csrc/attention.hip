@@ -860,7 +860,10 @@ static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     auto kern = attn64r_kernel<T>;
     SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
-    const int qsplit = (total_sb + 39) / 40;                  // <= 3 + 2 sub-blocks per wave, 8 waves
+    int qsplit = (total_sb + 39) / 40;                        // <= 3 + 2 sub-blocks per wave, 8 waves
+    // small batches (a single image: 5 crops x 16 heads = 80 workgroups on 256 CUs): two workgroups per (crop, head) fill the
+    // chip -- each stages the panel, but the CUs would idle otherwise (B = 5: 30 -> 17 us)
+    if ((long)a.heads * batch * qsplit * 2 <= num_cus() && total_sb >= 16) qsplit *= 2;
     a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
     hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(512), LDS, stream, a);
     SLIME_CHECK_LAUNCH("attention64r");

@@ -107,4 +107,14 @@ void slime_set_error(const char* fmt, ...);
         if (e_ != hipSuccess) { slime_set_error(what ": hipFuncSetAttribute: %s", hipGetErrorString(e_)); return SLIME_ELAUNCH; } \
     } while (0)
 
+// CU count of the current device (queried once; immutable afterwards): grid-quantisation rules count rounds of this many workgroups
+static inline int num_cus() {
+    static const int n = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    return n;
+}
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

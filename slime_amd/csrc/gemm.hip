@@ -69,16 +69,6 @@ __device__ __forceinline__ unsigned lds_byte_addr(const char* p) {
     return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }
 
-// CU count of the current device (queried once; immutable afterwards): grid-quantisation rules count rounds of this many workgroups
-static int num_cus() {
-    static const int n = [] {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
-    return n;
-}
-
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
@@ -1403,6 +1393,20 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
     }
     slime_set_error("gemm: unknown epilogue %d", epi);
     return SLIME_EINVAL;
+}
+
+// Name of the kernel instantiation slime_gemm dispatches to for a shape, as rocprofv3 prints it (bench.py labels its per-kernel
+// figures with it, so the bench line and the profiler summary name the same symbol).
+extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out, size_t out_len) {
+    SLIME_REQUIRE(out && out_len > 0 && M > 0 && N > 0 && K > 0, "gemm_kernel_name: bad input");
+    GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr};
+    const int tile = auto_tile(g);
+    const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
+    const int ktag = K >= 2048 ? 1 : 0;
+    if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
+    else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
+    else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, 1>", t, epilogue);
+    return SLIME_OK;
 }
 
 extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,

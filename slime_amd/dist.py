@@ -34,20 +34,95 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
 
 
 def sharded_tower(tower_fn: Callable[[torch.Tensor], torch.Tensor], crops: torch.Tensor, feat_shape: Tuple[int, int],
-                  feat_dtype: torch.dtype = torch.float32, group=None) -> torch.Tensor:
-    """Run ``tower_fn`` on this rank's block of ``crops`` ([N,3,S,S], identical on every rank) and
-    all-gather the features: returns [N, *feat_shape] on every rank."""
+                  feat_dtype: torch.dtype = torch.float32, group=None, chunk: int = 0) -> torch.Tensor:
+    """Run ``tower_fn`` on this rank's block of ``crops`` ([N,3,S,S], identical on every rank) and all-gather the
+    features: returns [N, *feat_shape] on every rank.
+
+    ``chunk`` > 0: the block is processed in micro-batches of ``chunk`` crops and every micro-batch is gathered with an
+    asynchronous collective as soon as its features exist, so the xGMI transfer of micro-batch j runs under the tower of
+    micro-batch j+1 (RCCL runs collectives on its own stream); only the last micro-batch's gather is exposed.  Same bytes,
+    same result (the tower is batch invariant), one extra strided copy per micro-batch into the output tensor."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return tower_fn(crops)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = crops.shape[0]
     lo, hi, per = shard_bounds(n, world, rank)
-    local = torch.zeros((per,) + tuple(feat_shape), dtype=feat_dtype, device=crops.device)
+    dev = crops.device
+    if chunk <= 0 or chunk >= per:
+        local = torch.zeros((per,) + tuple(feat_shape), dtype=feat_dtype, device=dev)
+        if hi > lo:
+            local[: hi - lo] = tower_fn(crops[lo:hi].contiguous()).to(feat_dtype)
+        gathered = torch.empty((world * per,) + tuple(feat_shape), dtype=feat_dtype, device=dev)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+        return gathered[:n]
+    out = torch.empty((world, per) + tuple(feat_shape), dtype=feat_dtype, device=dev)
+    pending = []
+    for j0 in range(0, per, chunk):                       # every rank walks the same micro-batches (short blocks pad with zeros)
+        cj = min(chunk, per - j0)
+        local = torch.zeros((cj,) + tuple(feat_shape), dtype=feat_dtype, device=dev)
+        a, b = lo + j0, min(lo + j0 + cj, hi)
+        if b > a:
+            local[: b - a] = tower_fn(crops[a:b].contiguous()).to(feat_dtype)
+        buf = torch.empty((world * cj,) + tuple(feat_shape), dtype=feat_dtype, device=dev)
+        work = dist.all_gather_into_tensor(buf, local, group=group, async_op=True)
+        pending.append((work, buf, j0, cj, local))
+    for work, buf, j0, cj, _keep in pending:
+        work.wait()
+        out[:, j0:j0 + cj] = buf.view(world, cj, *feat_shape)
+    return out.view(world * per, *feat_shape)[:n]
+
+
+def sharded_tower_compressed(tower_fn: Callable[[torch.Tensor], torch.Tensor], compress_fn: Callable[[torch.Tensor], torch.Tensor],
+                             crops: torch.Tensor, crops_per_image: int, feat_shape: Tuple[int, int], n_query: int,
+                             feat_dtype: torch.dtype = torch.bfloat16, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """SURVEY.md section 8e alternative: ``post_qformer`` is per-crop independent too, so every rank compresses the LOCAL crops
+    of its block before the exchange and the collective moves [., n_query, D] (144 rows) per local crop instead of the full
+    [., 576, D]; global crops (crop 0 of every ``crops_per_image``) travel uncompressed for the GatedBlock.  4x fewer bytes
+    for the local crops: (1 + 16) crops -> 576 + 16*144 rows instead of 17*576 (0.29x); (1 + 4) -> 0.40x.
+    Returns (global feats [n_images, *feat_shape], compressed local feats [n_local, n_query, D]) in crop order on every rank."""
+    n = crops.shape[0]
+    P, Dm = feat_shape
+    dev = crops.device
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        feats = tower_fn(crops).to(feat_dtype)
+        is_g = torch.arange(n, device=dev) % crops_per_image == 0
+        return feats[is_g], compress_fn(feats[~is_g]).to(feat_dtype)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = []
+    for r in range(world):
+        lo_r, hi_r, _ = shard_bounds(n, world, r)
+        g = sum(1 for c in range(lo_r, hi_r) if c % crops_per_image == 0)
+        counts.append((g, (hi_r - lo_r) - g))
+    gmax, lmax = max(c[0] for c in counts), max(c[1] for c in counts)
+    lo, hi, _ = shard_bounds(n, world, rank)
+    g_loc = torch.zeros((max(gmax, 1), P, Dm), dtype=feat_dtype, device=dev)
+    l_loc = torch.zeros((max(lmax, 1), n_query, Dm), dtype=feat_dtype, device=dev)
     if hi > lo:
-        local[: hi - lo] = tower_fn(crops[lo:hi].contiguous()).to(feat_dtype)
-    gathered = torch.empty((world * per,) + tuple(feat_shape), dtype=feat_dtype, device=crops.device)
-    dist.all_gather_into_tensor(gathered, local, group=group)
-    return gathered[:n]
+        feats = tower_fn(crops[lo:hi].contiguous()).to(feat_dtype)
+        is_g = (torch.arange(lo, hi, device=dev) % crops_per_image) == 0
+        if counts[rank][0]:
+            g_loc[: counts[rank][0]] = feats[is_g]
+        if counts[rank][1]:
+            l_loc[: counts[rank][1]] = compress_fn(feats[~is_g]).to(feat_dtype)
+    g_all = torch.empty((world * g_loc.shape[0], P, Dm), dtype=feat_dtype, device=dev)
+    l_all = torch.empty((world * l_loc.shape[0], n_query, Dm), dtype=feat_dtype, device=dev)
+    wg = dist.all_gather_into_tensor(g_all, g_loc, group=group, async_op=True)
+    wl = dist.all_gather_into_tensor(l_all, l_loc, group=group, async_op=True)
+    wg.wait(); wl.wait()
+    g_all = g_all.view(world, g_loc.shape[0], P, Dm)
+    l_all = l_all.view(world, l_loc.shape[0], n_query, Dm)
+    glob = torch.cat([g_all[r, : counts[r][0]] for r in range(world)], 0)
+    comp = torch.cat([l_all[r, : counts[r][1]] for r in range(world)], 0)
+    return glob, comp
+
+
+def gather_bytes(n_crops: int, crops_per_image: int, world: int, P: int = 576, n_query: int = 144, D: int = 1024, elem: int = 2):
+    """(bytes received per rank: full-feature gather, compressed-local gather) for the DESIGN.md section 7 table."""
+    per = -(-n_crops // world)
+    full = (world - 1) * per * P * D * elem
+    n_img = n_crops // crops_per_image
+    gper, lper = -(-n_img // world), -(-(n_crops - n_img) // world)
+    return full, (world - 1) * (gper * P + lper * n_query) * D * elem
 
 
 def sharded_tower_gather(local_feats: torch.Tensor, world: int, group=None) -> torch.Tensor:

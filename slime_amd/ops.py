@@ -220,6 +220,26 @@ def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[tor
     return (out, hidden) if want_hidden else out
 
 
+def gemm_kernel_name(M: int, N: int, K: int, dtype: torch.dtype, epilogue: int) -> str:
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    _lib.check(lib.slime_gemm_kernel_name(M, N, K, dtype_code(dtype), epilogue, buf, 128), "slime_gemm_kernel_name")
+    return buf.value.decode()
+
+
+def tower_kernel_names(pt: PackedTower, n_crops: int) -> Dict[int, str]:
+    """probe kernel id (include/slime_hip.h: slime_probe) -> rocprofv3 kernel name for a tower pass over n_crops crops."""
+    cfg = pt.cfg
+    M, D, Fi = n_crops * cfg.seq_len, cfg.hidden_size, cfg.intermediate_size
+    t = "F16" if pt.dtype == torch.float16 else "BF16"
+    return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T),
+            2: f"attn64r_kernel<{t}>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
+            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32),
+            5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T),
+            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32),
+            0: f"layernorm_kernel<{t}, {D // 64}>", 4: f"layernorm_kernel<{t}, {D // 64}>"}
+
+
 @dataclass
 class PackedResampler:
     dim: int
@@ -397,6 +417,25 @@ def adapter_forward(pg: PackedGated, post: Optional["PackedResampler"], feats: t
                                          pdesc, feats.data_ptr(), n_images, n_local, nw, nh, int(merge), out.data_ptr(),
                                          dtype_code(out.dtype), out.shape[1], base, ws.numel() - (base - ws.data_ptr()),
                                          _stream()), "slime_adapter_forward")
+    return out
+
+
+def adapter_forward_precompressed(pg: PackedGated, glob: torch.Tensor, comp: torch.Tensor, n_images: int, n_local: int, nw: int, nh: int,
+                                  merge: bool = True, learnable_gated: int = -1, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Adapter for the compressed-local exchange (slime_amd.dist.sharded_tower_compressed): ``glob`` T [B, 576, D] tower
+    features of the global views, ``comp`` T [B*n_local, q, D] local crops ALREADY through post_qformer.  Per-module sequence
+    (GatedBlock, projection MLP, batched merge) -- the arithmetic of adapter_forward after its post_qformer stage."""
+    lib = _lib.load()
+    B, P, q = n_images, glob.shape[1], comp.shape[1]
+    g = int(math.isqrt(q))
+    H = pg.mlp.hidden
+    out = torch.empty((B, P + n_local * q, H), dtype=out_dtype or glob.dtype, device=glob.device)
+    gt = gated_forward(pg, glob.float(), learnable_gated)                                   # fp32 [B, P, H]
+    loc = mlp_forward(pg.mlp, comp.reshape(-1, comp.shape[-1]).contiguous())               # fp32 [B*n_local*q, H]
+    _lib.check(lib.slime_merge_rows_batched(gt.data_ptr(), P, out.data_ptr(), dtype_code(out.dtype), out.shape[1], 0, B, P, 1, 1, H, 0,
+                                            _stream()), "slime_merge_rows_batched")
+    _lib.check(lib.slime_merge_rows_batched(loc.data_ptr(), n_local * q, out.data_ptr(), dtype_code(out.dtype), out.shape[1], P, B, nw,
+                                            nh, g, H, int(merge), _stream()), "slime_merge_rows_batched")
     return out
 
 

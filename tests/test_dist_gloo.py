@@ -20,7 +20,7 @@ def _worker(rank, world, port, n_crops, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from slime_amd import weights as W
-        from slime_amd.dist import sharded_tower, shard_bounds, sharded_tower_gather
+        from slime_amd.dist import sharded_tower, shard_bounds, sharded_tower_gather, sharded_tower_compressed
         from oracle import slime_oracle as O
         torch.set_num_threads(2)
         cfg = W.VisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1,
@@ -37,6 +37,19 @@ def _worker(rank, world, port, n_crops, q):
         got = sharded_tower(tower, px, (16, 64))
         lo, hi, per = shard_bounds(n_crops, world, rank)
         ok = torch.equal(got, full) and calls == ([hi - lo] if hi > lo else [])
+        # chunked (asynchronous, overlappable) gather: same tensor
+        for chunk in (1, 2):
+            ok = ok and torch.equal(sharded_tower(lambda x: O.tower_forward(sd, cfg, x), px, (16, 64), chunk=chunk), full)
+        # compressed-local variant: globals [., 16, 64] + pooled locals [., 4, 64] in crop order (a toy per-crop compress_fn)
+        per_image = 3 if n_crops % 3 == 0 else n_crops
+
+        def compress(x):
+            return x.view(x.shape[0], 4, 4, 64).mean(2)
+
+        glob, comp = sharded_tower_compressed(lambda x: O.tower_forward(sd, cfg, x), compress, px, per_image, (16, 64), 4,
+                                              torch.float32)
+        is_g = torch.arange(n_crops) % per_image == 0
+        ok = ok and torch.equal(glob, full[is_g]) and torch.equal(comp, compress(full[~is_g]))
         eq = sharded_tower_gather(torch.full((3, 2, 2), float(rank)), world)
         ok = ok and eq.shape[0] == 3 * world and all(float(eq[3 * r].mean()) == r for r in range(world))
         q.put((rank, bool(ok), lo, hi, per))
@@ -44,7 +57,7 @@ def _worker(rank, world, port, n_crops, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_crops", [5, 4, 1])
+@pytest.mark.parametrize("n_crops", [5, 4, 1, 6])
 def test_sharded_tower_world2(n_crops):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -72,3 +85,13 @@ def test_shard_bounds_cover_everything():
                 seen.extend(range(lo, hi))
             assert seen == list(range(n))
     assert image_shard(8, 8, 3) == [3] and image_shard(4, 8, 7) == []
+
+
+def test_gather_bytes_table():
+    """bytes received per rank, full-feature gather vs compressed-local gather."""
+    from slime_amd.dist import gather_bytes
+    full, comp = gather_bytes(68, 17, 8)
+    assert full == 7 * 9 * 576 * 1024 * 2 and comp == 7 * (1 * 576 + 8 * 144) * 1024 * 2
+    assert 0.25 < comp / full < 0.35
+    full, comp = gather_bytes(320, 5, 8)
+    assert comp / full < 0.45

@@ -148,3 +148,115 @@ def test_full_size_shard_invariance(dev):
     for shard in (5, 20):
         parts = torch.cat([vm.encode(px[i:i + shard].contiguous()) for i in range(0, 40, shard)])
         assert torch.equal(parts, full), shard
+
+
+# ------------------------------------------------------------------------------------------------ production sizes
+@pytest.fixture(scope="module")
+def full20():
+    """One CPU-oracle pass over 20 ViT-L/14-336 crops (~20-40 s on the GPU box's host cores), shared by the tests below.
+    Crops 0..16 are one BASELINE-config-3 image (1 global + 16 local crops, 4 x 4 grid); 17..19 fill the half batch."""
+    from slime_amd import weights as W
+    from oracle import slime_oracle as O
+    tsd = W.strip_tower_prefix(W.make_tower_state_dict(W.CLIP_L_336, seed=1234))
+    asd = W.make_adapter_state_dict(W.ADAPTER_8B, seed=4321)
+    px = W.synthetic_pixels(20, seed=77)
+    feats = O.tower_forward(tsd, W.CLIP_L_336, px)
+    return tsd, asd, px, feats
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_production_half_batch_tower_vs_oracle(dev, full20, dtype):
+    """the tower at its PRODUCTION launch shapes -- one 20-crop half batch, M = 11540 rows: four-wave
+    stream kernel for qkv / fc1, 256-row ping-pong for out_proj / fc2 (K = 4096 -> KTAG 1), attn64r -- against the fp32
+    oracle directly (not through a bit-equality chain), full tensors, bf16 and fp16."""
+    from slime_amd import ops, weights as W
+    tsd, _, px, ref = full20
+    pt = ops.pack_tower(tsd, W.CLIP_L_336, dtype, dev)
+    out = ops.tower_forward(pt, px.to(dev), out_dtype=torch.float32).cpu()
+    assert out.shape == ref.shape
+    assert rel_l2(out, ref) < TOL[dtype]
+    per_crop = ((out - ref).flatten(1).norm(dim=1) / ref.flatten(1).norm(dim=1))
+    assert float(per_crop.max()) < TOL[dtype] * 1.3, per_crop
+    per_tok = ((out - ref).norm(dim=-1) / ref.norm(dim=-1)).flatten()
+    assert float(per_tok.max()) < TOL[dtype] * 4, "no single token far off (a wrong tile would hide in the aggregate)"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config3_image_1_plus_16_crops_vs_oracle(dev, full20, dtype):
+    """BASELINE config 3's unit at real size: one image of 1 global + 16 local crops at ViT-L dims through the tower and the
+    FUSED adapter (GatedBlock on the global view, post_qformer + MLP + 4 x 4 spatial merge on the 16 local crops) against
+    the oracle stage by stage (llava_arch.py:212-255 order).  (The reference slicer never yields 16 local crops -- SURVEY
+    section 8d: the tensor is fed directly, the grid is explicit.)"""
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    tsd, asd, px, ref_feats = full20
+    A = W.ADAPTER_8B
+    pt = ops.pack_tower(tsd, W.CLIP_L_336, dtype, dev)
+    feats = ops.tower_forward(pt, px[:17].to(dev), out_dtype=dtype)
+    assert rel_l2(feats.float().cpu(), ref_feats[:17]) < TOL[dtype] * 1.2
+    pg = ops.pack_gated(W.sub_state(asd, "mm_projector."), A, dtype, dev)
+    post = ops.pack_resampler(W.sub_state(asd, "sampler.post_qformer."), 1024, 8, 576, dtype, dev, A.ln_eps)
+    tokens = ops.adapter_forward(pg, post, feats, 1, 16, 4, 4, True, -1, torch.float32)[0].cpu()      # [576 + 16*144, 4096]
+    proj_sd, post_sd = W.sub_state(asd, "mm_projector."), W.sub_state(asd, "sampler.post_qformer.")
+    g_ref = O.gated_block_forward(proj_sd, ref_feats[0], A.num_heads)
+    comp = O.resampler_forward(post_sd, ref_feats[1:17], A.num_heads, A.ln_eps)
+    merged_ref = O.spatial_merge(O.mlp_projector(proj_sd, comp), 4, 4, 12)
+    assert tokens.shape == (576 + 16 * 144, 4096)
+    assert rel_l2(tokens[:576], g_ref) < TOL[dtype] * 2
+    assert rel_l2(tokens[576:], merged_ref) < TOL[dtype] * 2
+
+
+def test_config3_68_crops_shard_invariance(dev):
+    """BASELINE config 3's batch (4 images x (1+16) = 68 crops) at full size: the product path's output equals, bit for bit,
+    the concatenation of the 8-GPU partition of SURVEY section 8e (blocks of ceil(68/8) = 9 crops, the last of 5) and is
+    deterministic -- the property that makes the sharded result identical to the 1-GPU result."""
+    from slime_amd import weights as W
+    from slime_amd.dist import shard_bounds
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
+    vm = HipCLIPVisionModel(W.CLIP_L_336)
+    vm.load_state_dict(W.make_tower_state_dict(W.CLIP_L_336, seed=1234))
+    vm.to(dev).to(torch.bfloat16)
+    px = W.synthetic_pixels(68, seed=19).to(dev).to(torch.bfloat16)
+    full = vm.encode(px)
+    assert full.shape == (68, 576, 1024) and torch.isfinite(full.float()).all()
+    parts = []
+    for r in range(8):
+        lo, hi, per = shard_bounds(68, 8, r)
+        assert per == 9 and hi - lo == (9 if r < 7 else 5)
+        parts.append(vm.encode(px[lo:hi].contiguous()))
+    assert torch.equal(torch.cat(parts), full)
+
+
+def outlier_tower_state(cfg, seed, scale):
+    """Seeded tower whose residual stream carries a few 'massive activation' channels (the shape real CLIP checkpoints have,
+    which N(0, sigma) weights hide): fc2 of layers 0 and L/2 gets +-`scale`/2 bias on 4 channels and 2 weight rows x `scale`."""
+    from slime_amd import weights as W
+    sd = W.strip_tower_prefix(W.make_tower_state_dict(cfg, seed=seed))
+    D = cfg.hidden_size
+    for layer in (0, cfg.num_hidden_layers // 2):
+        b = sd[f"encoder.layers.{layer}.mlp.fc2.bias"].clone()
+        w = sd[f"encoder.layers.{layer}.mlp.fc2.weight"].clone()
+        for j, ch in enumerate((5, D // 3, D // 2 + 1, D - 7)):
+            b[ch] = (scale / 2) * (1 if j % 2 == 0 else -1)
+        for ch in (11, D - 20):
+            w[ch] *= scale
+        sd[f"encoder.layers.{layer}.mlp.fc2.bias"], sd[f"encoder.layers.{layer}.mlp.fc2.weight"] = b, w
+    return sd
+
+
+@pytest.mark.parametrize("scale", [30.0, 100.0])
+def test_outlier_channel_stress(dev, scale):
+    """residual channels at x30 / x100 the typical magnitude.  fp32 residual stream + fp32 LayerNorm
+    statistics keep 16-bit operands within the stated per-stage tolerances (bf16 1.5e-2, fp16 3e-3) at both geometries."""
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    for cfg, n in ((W.TINY, 3), (W.CLIP_L_336, 2)):
+        sd = outlier_tower_state(cfg, 5, scale)
+        px = W.synthetic_pixels(n, seed=6)
+        ref, hs = O.tower_forward(sd, cfg, px), O.clip_hidden_states(sd, cfg, px, 1)
+        assert float(hs[1].abs().max()) > scale * 0.4, "the generator did produce outlier activations"
+        for dtype in (torch.float16, torch.bfloat16):
+            out = ops.tower_forward(ops.pack_tower(sd, cfg, dtype, dev), px.to(dev), out_dtype=torch.float32).cpu()
+            err = rel_l2(out, ref)
+            print(f"outlier x{scale:g} {'tiny' if cfg is W.TINY else 'ViT-L'} {dtype}: rel-L2 {err:.2e}")
+            assert torch.isfinite(out).all() and err < TOL[dtype], (cfg.hidden_size, dtype, err)
