@@ -46,7 +46,8 @@ enum {
     SLIME_EPI_BIAS_QUICKGELU_T,  /* x*sigmoid(1.702x) -> T                  (CLIP fc1, HF :346-350)      */
     SLIME_EPI_BIAS_GELU_T,       /* exact erf GELU -> T                     (projector/builder.py:53-57) */
     SLIME_EPI_BIAS_F32,          /* -> fp32                                                              */
-    SLIME_EPI_BIAS_RESID_F32     /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
+    SLIME_EPI_BIAS_RESID_F32,    /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
+    SLIME_EPI_BIAS_RESID_F32_LN  /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
 };
 
 int slime_abi_version(void);
@@ -61,6 +62,22 @@ const char* slime_last_error(void);
  * Replaces torch.nn.functional.linear / F.conv2d-as-GEMM on the path (HF :148-154,309-311,333,346-350). */
 int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
                int M, int N, int K, int dtype, int epilogue, void* stream);
+
+/* slime_gemm with LayerNorm FOLDED across two GEMMs (HF CLIPEncoderLayer :370-383: LN1 -> q/k/v, LN2 -> fc1), which removes
+ * the LayerNorm launches and the fp32 re-read of the residual stream from the tower:
+ *   producer (epilogue SLIME_EPI_BIAS_RESID_F32_LN, the out_proj / fc2 GEMM that updates the residual stream C): also writes
+ *     x16[M, ldx] = T(C) and stats_out[M, N/64, 2] = (sum, sum of squares) of the ROUNDED row over each 64-column group;
+ *   consumer (ln_stats != NULL; epilogue BIAS_T or BIAS_QUICKGELU_T): A = x16 (un-normalised), B = W . diag(gamma) rounded to T,
+ *     bias = b + W beta, ln_colsum[n] = sum_k B[n, k]; the epilogue evaluates rstd * (acc - mu * ln_colsum[n]) + bias[n] with
+ *     mu / rstd = rsqrt(var + ln_eps) from the ln_groups partial sums of each row (K = the normalised width).
+ * Identical to LayerNorm followed by the GEMM up to rounding (x is rounded to T before instead of after the normalisation). */
+typedef struct {
+    const void* A; int lda; const void* B; const float* bias; void* C; int ldc;
+    int M, N, K, dtype, epilogue;
+    const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;     /* consumer side, or NULL / 0 */
+    void* x16; int ldx; float* stats_out;                                             /* producer side, or NULL / 0 */
+} slime_gemm_args;
+int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 
 /* Name (as rocprofv3 prints it) of the kernel instantiation slime_gemm launches for this shape: host-only query. */
 int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out_host, size_t out_len);
@@ -82,9 +99,12 @@ int slime_im2col(const void* pixels, int pix_dtype, void* out, int n, int image,
                  int dtype, void* stream);
 
 /* h[n, 1+P, D] = pre_layrnorm( cat(class_embedding, patch_out[n, P, D]) + position_embedding )
- * (HF CLIPVisionEmbeddings.forward :212-217 + pre_layrnorm :642).  fp32 in/out. */
+ * (HF CLIPVisionEmbeddings.forward :212-217 + pre_layrnorm :642).  fp32 in/out.  If x16 / stats are non-NULL it also
+ * prepares the first folded LayerNorm of the layer stack (slime_gemm_ex): x16 T [n*(1+P), D] = T(h) and
+ * stats [n*(1+P), D/64, 2] = (sum, sum of squares) of the rounded rows per 64-column group. */
 int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
-                        const float* ln_b, float eps, float* h, int n, int P, int D, void* stream);
+                        const float* ln_b, float eps, float* h, void* x16, float* stats, int dtype, int n, int P, int D,
+                        void* stream);
 
 /* Fused multi-head attention, softmax(Q K^T) V with fp32 online softmax; Q is expected PRE-SCALED
  * by head_dim^-0.5 * log2(e) (SLIME_ATTN_Q_PRESCALE, folded into the q projection weights and bias at pack
@@ -207,21 +227,25 @@ typedef struct {
     const float* cls;                       /* f32 [hidden]                                               */
     const float* pos;                       /* f32 [1+P, hidden]                                          */
     const float* pre_ln_w; const float* pre_ln_b;
-    /* per-layer tensors, contiguous over layers (layer stride = the per-layer element count) */
-    const float* ln1_w; const float* ln1_b; /* f32 [L, hidden]                                            */
-    const void*  w_qkv;                     /* T   [L, 3*hidden, hidden], q rows x dh^-0.5*log2(e)       */
-    const float* b_qkv;                     /* f32 [L, 3*hidden]          (q part scaled likewise)        */
-    const void*  w_o;   const float* b_o;   /* T   [L, hidden, hidden]; f32 [L, hidden]                   */
-    const float* ln2_w; const float* ln2_b;
-    const void*  w_fc1; const float* b_fc1; /* T   [L, inter, hidden];  f32 [L, inter]                    */
-    const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                   */
+    /* per-layer tensors, contiguous over layers (layer stride = the per-layer element count).  layer_norm1 / layer_norm2
+     * are FOLDED into the q/k/v and fc1 GEMMs at pack time (slime_gemm_ex): W' = W . diag(gamma), b' = b + W beta,
+     * colsum[n] = sum_k T(W')[n, k]. */
+    const void*  w_qkv;                     /* T   [L, 3*hidden, hidden] = Wqkv . diag(ln1_w), q rows x dh^-0.5*log2(e)     */
+    const float* b_qkv;                     /* f32 [L, 3*hidden] = b + Wqkv ln1_b   (q part scaled likewise)               */
+    const float* colsum_qkv;                /* f32 [L, 3*hidden]                                                          */
+    const void*  w_o;   const float* b_o;   /* T   [L, hidden, hidden]; f32 [L, hidden]                                   */
+    const void*  w_fc1;                     /* T   [L, inter, hidden] = W1 . diag(ln2_w)                                  */
+    const float* b_fc1;                     /* f32 [L, inter] = b + W1 ln2_b                                              */
+    const float* colsum_fc1;                /* f32 [L, inter]                                                             */
+    const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                                   */
 } slime_vit_desc;
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
 
 /* Optional in-situ timing probe: slime_vit_forward_ex records the HIP events `start` / `stop` (hipEvent_t,
  * owned by the caller) immediately before / after the launch of one kernel of one layer, on the call's
- * stream.  kernel: 0 LN1, 1 qkv GEMM, 2 attention, 3 out_proj GEMM, 4 LN2, 5 fc1 GEMM, 6 fc2 GEMM. */
+ * stream.  kernel: 1 qkv GEMM, 2 attention, 3 out_proj GEMM, 5 fc1 GEMM, 6 fc2 GEMM (0 and 4 were the LayerNorm
+ * launches of ABI 1; they are folded into the GEMMs now and never fire). */
 typedef struct { int layer; int kernel; void* start; void* stop; } slime_probe;
 
 /* pixels [n,3,image,image] -> out [n, P(+1 if keep_cls), hidden] in out_dtype (BF16/F16/F32).

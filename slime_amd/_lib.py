@@ -24,7 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 2
 BF16, F16, F32, U8 = 0, 1, 2, 3
-EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32 = range(5)
+EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN = range(6)
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -34,9 +34,16 @@ class VitDesc(C.Structure):
                 ("image", c_int), ("patch", c_int), ("kpad", c_int), ("dtype", c_int), ("eps", c_float),
                 ("patch_w", c_void_p), ("cls", c_void_p), ("pos", c_void_p),
                 ("pre_ln_w", c_void_p), ("pre_ln_b", c_void_p),
-                ("ln1_w", c_void_p), ("ln1_b", c_void_p), ("w_qkv", c_void_p), ("b_qkv", c_void_p),
-                ("w_o", c_void_p), ("b_o", c_void_p), ("ln2_w", c_void_p), ("ln2_b", c_void_p),
-                ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p)]
+                ("w_qkv", c_void_p), ("b_qkv", c_void_p), ("colsum_qkv", c_void_p),
+                ("w_o", c_void_p), ("b_o", c_void_p),
+                ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("colsum_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_int),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
+                ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
+                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p)]
 
 
 class ResamplerDesc(C.Structure):
@@ -70,7 +77,8 @@ _SIGNATURES = {
     "slime_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "slime_im2col": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "slime_embed_prenorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int,
+    "slime_gemm_ex": (c_int, [_P(GemmArgs), c_void_p]),
+    "slime_embed_prenorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_int, c_int, c_void_p]),
     "slime_attention": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
                                 c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -32,7 +32,7 @@ static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
 // CLIP tower
 // ------------------------------------------------------------------------------------------------
 struct VitPlan {
-    size_t xn, qkv, ctx, ff, h, total;   // offsets
+    size_t xn, qkv, ctx, ff, h, stats, total;   // offsets
 };
 
 static VitPlan vit_plan(const slime_vit_desc* d, int n) {
@@ -49,6 +49,7 @@ static VitPlan vit_plan(const slime_vit_desc* d, int n) {
     const size_t ff_bytes = M * (size_t)d->inter * 2;
     const size_t pe_bytes = align_up(Mp * (size_t)d->kpad * 2, 256) + Mp * D * 4;
     p.ff = take(ff_bytes > pe_bytes ? ff_bytes : pe_bytes);
+    p.stats = take(M * (D / 64) * 2 * sizeof(float));      // LayerNorm fold: (sum, sum of squares) per row and 64-column group
     p.total = align_up(off, 256);
     return p;
 }
@@ -57,14 +58,15 @@ static int vit_validate(const slime_vit_desc* d) {
     SLIME_REQUIRE(d, "vit: null descriptor");
     SLIME_REQUIRE(is16(d->dtype), "vit: dtype must be BF16 or F16");
     SLIME_REQUIRE(d->hidden == 128 || d->hidden == 256 || d->hidden == 1024, "vit: hidden=%d unsupported", d->hidden);
+    SLIME_REQUIRE(d->hidden % 64 == 0, "vit: hidden must be a multiple of 64 (LayerNorm partial sums per 64 columns)");
     SLIME_REQUIRE(d->heads > 0 && d->hidden % d->heads == 0 && d->hidden / d->heads == 64, "vit: head_dim must be 64");
     SLIME_REQUIRE(d->inter % 128 == 0 && d->inter % 64 == 0, "vit: intermediate size %d must be a multiple of 128", d->inter);
     SLIME_REQUIRE(d->image % d->patch == 0, "vit: image %d not a multiple of patch %d", d->image, d->patch);
     SLIME_REQUIRE(d->kpad % 64 == 0 && d->kpad >= 3 * d->patch * d->patch, "vit: kpad=%d", d->kpad);
     SLIME_REQUIRE(d->layers_run >= 0, "vit: layers_run < 0");
     SLIME_REQUIRE(d->patch_w && d->cls && d->pos && d->pre_ln_w && d->pre_ln_b, "vit: missing embedding weights");
-    SLIME_REQUIRE(d->layers_run == 0 || (d->ln1_w && d->ln1_b && d->w_qkv && d->b_qkv && d->w_o && d->b_o && d->ln2_w &&
-                                         d->ln2_b && d->w_fc1 && d->b_fc1 && d->w_fc2 && d->b_fc2), "vit: missing layer weights");
+    SLIME_REQUIRE(d->layers_run == 0 || (d->w_qkv && d->b_qkv && d->colsum_qkv && d->w_o && d->b_o && d->w_fc1 && d->b_fc1 &&
+                                         d->colsum_fc1 && d->w_fc2 && d->b_fc2), "vit: missing layer weights");
     return SLIME_OK;
 }
 
@@ -120,27 +122,53 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
     float* pe_out = (float*)((char*)ff + align_up((size_t)Mp * d->kpad * 2, 256));
     const int dt = d->dtype;
 
-    // patch embed (conv as GEMM), class token, position table, pre-LayerNorm
+    float* stats = (float*)(w + p.stats);
+    const int G = D / 64;
+
+    // patch embed (conv as GEMM), class token, position table, pre-LayerNorm (which also prepares layer 0's folded LN1)
     TRY(slime_im2col(pixels, pix_dtype, a_pe, n, d->image, d->patch, d->kpad, dt, stream));
     TRY(slime_gemm(a_pe, d->kpad, d->patch_w, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
-    TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, n, P, D, stream));
+    TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, d->layers_run > 0 ? xn : nullptr,
+                            d->layers_run > 0 ? stats : nullptr, dt, n, P, D, stream));
 
+    // Layer loop, 5 launches per layer.  Both LayerNorms are FOLDED into the GEMMs around them (slime_gemm_ex): the GEMM that
+    // updates the residual stream (previous fc2 / out_proj, or the embedding kernel) leaves the rows rounded to T (`xn`) and
+    // their partial sums (`stats`); the q/k/v and fc1 GEMMs run on those un-normalised rows with gamma folded into their
+    // weights and apply mean / rstd in the epilogue.  No LayerNorm kernel, no fp32 re-read of the residual stream.
     for (int l = 0; l < d->layers_run; ++l) {
         const char* w_qkv = (const char*)d->w_qkv + (size_t)l * 3 * D * D * 2;
         const char* w_o = (const char*)d->w_o + (size_t)l * D * D * 2;
         const char* w_fc1 = (const char*)d->w_fc1 + (size_t)l * F * D * 2;
         const char* w_fc2 = (const char*)d->w_fc2 + (size_t)l * D * F * 2;
-        PROBED(0, slime_layernorm(h, D, M, D, d->ln1_w + (size_t)l * D, d->ln1_b + (size_t)l * D, d->eps, 1, nullptr, xn,
-                                  nullptr, nullptr, 0, dt, stream));
-        PROBED(1, slime_gemm(xn, D, w_qkv, d->b_qkv + (size_t)l * 3 * D, qkv, 3 * D, M, 3 * D, D, dt, SLIME_EPI_BIAS_T, stream));
+        const bool last = l + 1 == d->layers_run;
+        slime_gemm_args ga{};
+        ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
+        // q/k/v = LN1(h) Wqkv^T + b  (HF :370-371, :309-311)
+        ga.A = xn; ga.lda = D; ga.B = w_qkv; ga.bias = d->b_qkv + (size_t)l * 3 * D; ga.C = qkv; ga.ldc = 3 * D; ga.N = 3 * D; ga.K = D;
+        ga.epilogue = SLIME_EPI_BIAS_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_qkv + (size_t)l * 3 * D;
+        PROBED(1, slime_gemm_ex(&ga, stream));
         PROBED(2, slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
                                   qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
                                   dt, stream));
-        PROBED(3, slime_gemm(ctx, D, w_o, d->b_o + (size_t)l * D, h, D, M, D, D, dt, SLIME_EPI_BIAS_RESID_F32, stream));
-        PROBED(4, slime_layernorm(h, D, M, D, d->ln2_w + (size_t)l * D, d->ln2_b + (size_t)l * D, d->eps, 1, nullptr, xn,
-                                  nullptr, nullptr, 0, dt, stream));
-        PROBED(5, slime_gemm(xn, D, w_fc1, d->b_fc1 + (size_t)l * F, ff, F, M, F, D, dt, SLIME_EPI_BIAS_QUICKGELU_T, stream));
-        PROBED(6, slime_gemm(ff, F, w_fc2, d->b_fc2 + (size_t)l * D, h, D, M, D, F, dt, SLIME_EPI_BIAS_RESID_F32, stream));
+        // h += ctx Wo^T + b; leaves T(h) and its partial sums for LN2  (HF :372-377)
+        ga = slime_gemm_args{};
+        ga.M = M; ga.dtype = dt;
+        ga.A = ctx; ga.lda = D; ga.B = w_o; ga.bias = d->b_o + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = D;
+        ga.epilogue = SLIME_EPI_BIAS_RESID_F32_LN; ga.x16 = xn; ga.ldx = D; ga.stats_out = stats;
+        PROBED(3, slime_gemm_ex(&ga, stream));
+        // ff = quick_gelu(LN2(h) W1^T + b)  (HF :379-380, :346-350)
+        ga = slime_gemm_args{};
+        ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
+        ga.A = xn; ga.lda = D; ga.B = w_fc1; ga.bias = d->b_fc1 + (size_t)l * F; ga.C = ff; ga.ldc = F; ga.N = F; ga.K = D;
+        ga.epilogue = SLIME_EPI_BIAS_QUICKGELU_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_fc1 + (size_t)l * F;
+        PROBED(5, slime_gemm_ex(&ga, stream));
+        // h += ff W2^T + b; prepares the next layer's LN1 unless this is the last layer that runs  (HF :381-383)
+        ga = slime_gemm_args{};
+        ga.M = M; ga.dtype = dt;
+        ga.A = ff; ga.lda = F; ga.B = w_fc2; ga.bias = d->b_fc2 + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = F;
+        ga.epilogue = last ? SLIME_EPI_BIAS_RESID_F32 : SLIME_EPI_BIAS_RESID_F32_LN;
+        if (!last) { ga.x16 = xn; ga.ldx = D; ga.stats_out = stats; }
+        PROBED(6, slime_gemm_ex(&ga, stream));
     }
     if (out) {
         // feature_select: 'patch' drops the class token (clip_encoder.py:38-39), cast to out dtype (:52,56)

@@ -35,7 +35,48 @@ struct GemmArgs {
     int lda, ldc, M, N, K;
     int group_m;      // row tiles per L2 patch of the ping-pong kernel (0 = default 4)
     unsigned long long* dbg;   // ABL & 8 builds only: 4 s_memtime stamps per workgroup
+    // LayerNorm folded into this GEMM (consumer side; epilogues BIAS_T / BIAS_QUICKGELU_T): A holds the UN-normalised 16-bit rows x,
+    // B = W . diag(gamma), bias = b + W beta, and the epilogue applies  rstd * (acc - mu * colsum[n]) + bias[n]  with the row
+    // statistics (mu, rstd) finalised per workgroup from the producer's per-64-column partial sums.  NULL = plain GEMM.
+    const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;
+    // producer side (epilogue BIAS_RESID_F32_LN): 16-bit copy of the updated residual rows and their partial sums
+    char* x16; int ldx; float* stats_out;
 };
+
+// Sum over the four 16-lane rows of a wave (lanes l, l+16, l+32, l+48), result in every row: pure VALU (permlane swaps).
+__device__ __forceinline__ float rows4_allsum(float x) {
+    const unsigned u = __float_as_uint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned w = __float_as_uint(y);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Consumer side of the LayerNorm fold: (rstd, -mu * rstd) of the BM rows of this workgroup's tile -> LDS, from the producer's
+// partial sums (sum x, sum x^2 per 64-column group, summed here in a FIXED order: results do not depend on the tile shape
+// of either kernel).  Ordinary loads, issued before any LDS-DMA of the prologue.  var = E[x^2] - mu^2 in fp32: sound while
+// |mu| is not orders of magnitude above sigma (residual streams are not; tests/test_gpu_path.py stresses x100 outliers).
+template <int BM, int NT>
+__device__ __forceinline__ void stage_ln_rows(const GemmArgs& g, const int m0, float* lnrow) {
+    if (!g.ln_stats) return;
+    for (int r = threadIdx.x; r < BM; r += NT) {
+        const int row = m0 + r;
+        float rstd = 0.f, nmr = 0.f;
+        if (row < g.M) {
+            const float2* st = reinterpret_cast<const float2*>(g.ln_stats) + (size_t)row * g.ln_groups;
+            float sx = 0.f, sq = 0.f;
+            for (int i = 0; i < g.ln_groups; ++i) { const float2 v = st[i]; sx += v.x; sq += v.y; }
+            const float inv = 1.0f / (float)g.K;
+            const float mu = sx * inv;
+            const float var = fmaxf(sq * inv - mu * mu, 0.f);
+            rstd = rsqrtf(var + g.ln_eps);
+            nmr = -mu * rstd;
+        }
+        lnrow[2 * r] = rstd; lnrow[2 * r + 1] = nmr;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the prologue's barrier publishes the table to the other waves
+}
 
 // erf-form GELU 0.5 x (1 + erf(x / sqrt 2)).  The device-library erff is a large branchy routine (it
 // put 1.2 KB of scratch into this epilogue and ran the projector GEMM at 114 TF/s); this is the
@@ -83,8 +124,10 @@ template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIM
 //   * the bias is loaded once up front; results are formed in place in the accumulators (distinct
 //     registers per store) and stored back to back;
 //   * the fp32 residual is fetched in register double-buffered batches, one batch ahead of the stores.
-template <typename T, int EPI, int MI, int NI, bool FULL>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI][NI], const int row_base, const int col_base) {
+// LN (consumer side of the LayerNorm fold): lnrow points at this lane's first row of the workgroup's (rstd, -mu rstd) table.
+template <typename T, int EPI, int MI, int NI, bool FULL, bool LN = false>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI][NI], const int row_base, const int col_base,
+                                              const float* lnrow = nullptr) {
     constexpr int NP = NI / 2;
     float bias[NP][8];
 #pragma unroll
@@ -100,7 +143,47 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
         }
     }
     auto in_range = [&](int row) { return FULL || row < g.M; };
-    if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32) {
+    if constexpr (LN) {
+        // LayerNorm-fold epilogues (BIAS_T / BIAS_QUICKGELU_T only): pre-activation = rstd[m] * (acc - mu[m] * colsum[n]) + bias[n],
+        // evaluated as fma(rstd, acc, fma(-mu rstd, colsum, bias)).  Everything that is loaded (bias, colsum, the row table) is
+        // fetched up front; each 8-column group is then read from the accumulators, finished and stored at once, so only 8
+        // results are live at a time (the in-place form below keeps all of them in VGPRs, which spills next to 64 constants).
+        static_assert(EpiOutIsT<EPI>::value, "LayerNorm fold: T outputs only");
+        float cs[NP][8];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const float4 c0 = *reinterpret_cast<const float4*>(g.ln_colsum + col_base + 32 * p);
+            const float4 c1 = *reinterpret_cast<const float4*>(g.ln_colsum + col_base + 32 * p + 4);
+            cs[p][0] = c0.x; cs[p][1] = c0.y; cs[p][2] = c0.z; cs[p][3] = c0.w;
+            cs[p][4] = c1.x; cs[p][5] = c1.y; cs[p][6] = c1.z; cs[p][7] = c1.w;
+        }
+        float2 rn[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) rn[i] = *reinterpret_cast<const float2*>(lnrow + 32 * i);   // rows 16 apart, 2 floats each
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = row_base + i * 16;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = fmaf(rn[i].x, acc[i][2 * p][j], fmaf(rn[i].y, cs[p][j], bias[p][j]));
+                    v[4 + j] = fmaf(rn[i].x, acc[i][2 * p + 1][j], fmaf(rn[i].y, cs[p][4 + j], bias[p][4 + j]));
+                }
+                if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+                    constexpr float C = -1.702f * 1.4426950408889634f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(C * v[j]));
+                }
+                const u32x4 w = pack8<T>(v);
+                if (in_range(row))
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = w;
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32 || EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
         constexpr int BATCH = (MI >= 2) ? 2 : 1;          // 16-row steps per residual batch
         constexpr int NB = MI / BATCH;
         float4 hb[2][BATCH][NP][2];
@@ -137,6 +220,35 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                         float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
                         *reinterpret_cast<f32x4*>(o) = acc[i][2 * p];
                         *reinterpret_cast<f32x4*>(o + 4) = acc[i][2 * p + 1];
+                    }
+                }
+                if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
+                    // the next GEMM's A operand: the updated rows rounded to T, and the partial sums of the ROUNDED values
+                    // (what that GEMM multiplies) per 64-column group = lane-local over the pair of 32-column blocks, then
+                    // across the wave's four 16-lane rows; same order in every kernel of this file
+#pragma unroll
+                    for (int pp = 0; pp < NP / 2; ++pp) {
+                        float sx = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const int p = 2 * pp + h2;
+                            u32x4 w;
+                            w[0] = T::pack2(acc[i][2 * p][0], acc[i][2 * p][1]); w[1] = T::pack2(acc[i][2 * p][2], acc[i][2 * p][3]);
+                            w[2] = T::pack2(acc[i][2 * p + 1][0], acc[i][2 * p + 1][1]); w[3] = T::pack2(acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]);
+                            if (in_range(row))
+                                *reinterpret_cast<u32x4*>(g.x16 + ((size_t)row * g.ldx + col_base + 32 * p) * 2) = w;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float lo = T::lo(w[k]), hi = T::hi(w[k]);
+                                sx += lo; sx += hi;
+                                sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq);
+                            }
+                        }
+                        sx = rows4_allsum(sx);
+                        sq = rows4_allsum(sq);
+                        // col_base = (first column of the wave's 64-aligned span) + 8 * (lane >> 4): lane row 0 writes
+                        if ((col_base & 31) == 0 && in_range(row))
+                            *reinterpret_cast<float2*>(g.stats_out + ((size_t)row * (g.N >> 6) + ((col_base + 64 * pp) >> 6)) * 2) = make_float2(sx, sq);
                     }
                 }
             }
@@ -195,6 +307,23 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
             }
         }
     }
+}
+
+// Epilogue dispatch shared by every kernel: FULL-tile fast path or ragged last row tile; LayerNorm-fold variant when the call
+// carries row statistics (only the two epilogues the tower uses it with are instantiated).
+template <typename T, int EPI, int MI, int NI>
+__device__ __forceinline__ void run_epilogue(const GemmArgs& g, f32x4 (&acc)[MI][NI], const int row_base, const int col_base,
+                                             const bool full, const float* lnrow_lane) {
+    constexpr bool CAN_LN = (EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T);
+    if constexpr (CAN_LN) {
+        if (g.ln_stats) {
+            if (full) epilogue_wave<T, EPI, MI, NI, true, true>(g, acc, row_base, col_base, lnrow_lane);
+            else epilogue_wave<T, EPI, MI, NI, false, true>(g, acc, row_base, col_base, lnrow_lane);
+            return;
+        }
+    }
+    if (full) epilogue_wave<T, EPI, MI, NI, true>(g, acc, row_base, col_base);
+    else epilogue_wave<T, EPI, MI, NI, false>(g, acc, row_base, col_base);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
@@ -281,6 +410,8 @@ gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float* lnrow = reinterpret_cast<float*>(smem + 2 * STAGE);
+    stage_ln_rows<BM, NW * 64>(g, m0, lnrow);
     const int nk = g.K / BK;
     stage(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -332,8 +463,8 @@ gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane holds, per (mi, tile pair), 8 consecutive columns of one row ------------
-    if (m0 + BM <= g.M) epilogue_wave<T, EPI, MI, NI, true>(g, acc, m0 + wm * TM + (lane & 15), n0 + wn * TN + 8 * (lane >> 4));
-    else epilogue_wave<T, EPI, MI, NI, false>(g, acc, m0 + wm * TM + (lane & 15), n0 + wn * TN + 8 * (lane >> 4));
+    run_epilogue<T, EPI, MI, NI>(g, acc, m0 + wm * TM + (lane & 15), n0 + wn * TN + 8 * (lane >> 4), m0 + BM <= g.M,
+                                 lnrow + 2 * (wm * TM + (lane & 15)));
 }
 
 
@@ -459,6 +590,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float* lnrow = reinterpret_cast<float*>(smem + 2 * STAGE);
+    stage_ln_rows<BM, 512>(g, m0, lnrow);
     const int nk = g.K / BK;
     // ---- prologue: all of tile 0, and the tile-1 pieces that "earlier" sections would have issued
     issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
@@ -527,8 +660,8 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
     if constexpr ((ABL & 8) != 0) t_loop = __builtin_amdgcn_s_memtime();
 
-    if (m0 + BM <= g.M) epilogue_wave<T, EPI, 2 * MT, 4, true>(g, acc, m0 + grp * HALF + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
-    else epilogue_wave<T, EPI, 2 * MT, 4, false>(g, acc, m0 + grp * HALF + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4));
+    run_epilogue<T, EPI, 2 * MT, 4>(g, acc, m0 + grp * HALF + (lane & 15), n0 + wn * 64 + 8 * (lane >> 4), m0 + BM <= g.M,
+                                    lnrow + 2 * (grp * HALF + (lane & 15)));
     if constexpr ((ABL & 8) != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0 && g.dbg) {
@@ -639,6 +772,8 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    float* lnrow = reinterpret_cast<float*>(smem + 2 * STAGE + 64);
+    stage_ln_rows<BM, 256>(g, m0, lnrow);
     const int nk = g.K / BK;
     // ---- prologue ----
 #pragma unroll
@@ -734,8 +869,7 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
-    if (m0 + BM <= g.M) epilogue_wave<T, EPI, MI, 8, true>(g, acc, m0 + wm * WM + li, n0 + wn * 128 + 8 * lq);
-    else epilogue_wave<T, EPI, MI, 8, false>(g, acc, m0 + wm * WM + li, n0 + wn * 128 + 8 * lq);
+    run_epilogue<T, EPI, MI, 8>(g, acc, m0 + wm * WM + li, n0 + wn * 128 + 8 * lq, m0 + BM <= g.M, lnrow + 2 * (wm * WM + li));
 }
 
 
@@ -916,7 +1050,7 @@ __global__ void __launch_bounds__(512) gemm_ppp_kernel(GemmArgs g) {
         if (grp == 0) PP_BARRIER();                          // balance group 1's extra barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA for the next tile has landed
         if (cur.m0 + BM <= g.M) epilogue_wave<T, EPI, 8, 4, true>(g, acc, cur.m0 + grp * 128 + (lane & 15), cur.n0 + wn * 64 + 8 * (lane >> 4));
-        else epilogue_wave<T, EPI, 8, 4, false>(g, acc, cur.m0 + grp * 128 + (lane & 15), cur.n0 + wn * 64 + 8 * (lane >> 4));
+        else epilogue_wave<T, EPI, 8, 4, false>(g, acc, cur.m0 + grp * 128 + (lane & 15), cur.n0 + wn * 64 + 8 * (lane >> 4));   // (no LayerNorm fold in this variant)
         if (!has_next) break;
         cur = nxt;
         L = Ln;
@@ -1240,7 +1374,7 @@ static constexpr unsigned long long* g_dbg = nullptr;
 template <typename T, int EPI, int KTAG, int ABL, int MT = 4>
 static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 64 * MT;
-    constexpr int LDS = 2 * (BM + 256) * 64 * 2;
+    constexpr int LDS = 2 * (BM + 256) * 64 * 2 + BM * 8;           // + the (rstd, -mu rstd) table of the LayerNorm fold
     auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL, MT>;
     SLIME_SET_LDS_ONCE(kern, LDS, "gemm_pp");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
@@ -1270,7 +1404,7 @@ static int launch_pp(const GemmArgs& g, hipStream_t stream) {
 template <typename T, int EPI, int KTAG, int MI, int ABL = 0>
 static int launch_w4_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 32 * MI;
-    constexpr int LDS = 2 * (BM + 256) * 64 * 2 + 64;               // + the split-barrier counter
+    constexpr int LDS = 2 * (BM + 256) * 64 * 2 + 64 + BM * 8;      // + the split-barrier counter + the LayerNorm-fold row table
     auto kern = gemm_w4_kernel<T, EPI, KTAG, MI, ABL>;
     SLIME_SET_LDS_ONCE(kern, LDS, "gemm_w4");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
@@ -1305,7 +1439,7 @@ static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * 64 * 2;
-    constexpr int LDS = 2 * STAGE;
+    constexpr int LDS = 2 * STAGE + BM * 8;                         // + the LayerNorm-fold row table
     auto kern = gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, EPI, SCHED>;
     SLIME_SET_LDS_ONCE(kern, LDS, "gemm");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
@@ -1368,6 +1502,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
     if (tile == 6 || tile == 8) tile = 7;
+    if (tile == 7 && EPI == SLIME_EPI_BIAS_RESID_F32_LN) tile = 4;     // the 32x32 variant has no LayerNorm-fold epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
@@ -1390,6 +1525,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
         case SLIME_EPI_BIAS_GELU_T: return launch_epi<T, SLIME_EPI_BIAS_GELU_T>(g, stream);
         case SLIME_EPI_BIAS_F32: return launch_epi<T, SLIME_EPI_BIAS_F32>(g, stream);
         case SLIME_EPI_BIAS_RESID_F32: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32>(g, stream);
+        case SLIME_EPI_BIAS_RESID_F32_LN: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32_LN>(g, stream);
     }
     slime_set_error("gemm: unknown epilogue %d", epi);
     return SLIME_EINVAL;
@@ -1399,7 +1535,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
 // figures with it, so the bench line and the profiler summary name the same symbol).
 extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out, size_t out_len) {
     SLIME_REQUIRE(out && out_len > 0 && M > 0 && N > 0 && K > 0, "gemm_kernel_name: bad input");
-    GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr};
+    GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
@@ -1409,19 +1545,38 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     return SLIME_OK;
 }
 
-extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
-                          int M, int N, int K, int dtype, int epilogue, void* stream) {
-    SLIME_REQUIRE(A && B && C, "gemm: null pointer");
+extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
+    SLIME_REQUIRE(a, "gemm: null argument block");
+    const int M = a->M, N = a->N, K = a->K, lda = a->lda, ldc = a->ldc;
+    SLIME_REQUIRE(a->A && a->B && a->C, "gemm: null pointer");
     SLIME_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty shape M=%d N=%d K=%d", M, N, K);
     SLIME_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
     SLIME_REQUIRE(N % 128 == 0, "gemm: N=%d must be a multiple of 128", N);
     SLIME_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm: bad leading dims lda=%d ldc=%d", lda, ldc);
-    SLIME_REQUIRE(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) &&
-                  (!bias || (uintptr_t)bias % 16 == 0), "gemm: pointers must be 16-byte aligned");
-    GemmArgs g{(const char*)A, (const char*)B, bias, C, lda, ldc, M, N, K, g_group_m, g_dbg};
+    SLIME_REQUIRE(((uintptr_t)a->A % 16 == 0) && ((uintptr_t)a->B % 16 == 0) && ((uintptr_t)a->C % 16 == 0) &&
+                  (!a->bias || (uintptr_t)a->bias % 16 == 0), "gemm: pointers must be 16-byte aligned");
+    if (a->ln_stats) {
+        SLIME_REQUIRE(a->epilogue == SLIME_EPI_BIAS_T || a->epilogue == SLIME_EPI_BIAS_QUICKGELU_T,
+                      "gemm: the LayerNorm fold is built for the BIAS_T / BIAS_QUICKGELU_T epilogues");
+        SLIME_REQUIRE(a->ln_colsum && a->ln_groups > 0 && ((uintptr_t)a->ln_colsum % 16) == 0 && ((uintptr_t)a->ln_stats % 8) == 0,
+                      "gemm: LayerNorm fold needs ln_colsum [N] and ln_groups partial sums per row");
+    }
+    if (a->epilogue == SLIME_EPI_BIAS_RESID_F32_LN)
+        SLIME_REQUIRE(a->x16 && a->stats_out && a->ldx >= N && a->ldx % 8 == 0 && ((uintptr_t)a->x16 % 16) == 0 &&
+                      ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0, "gemm: BIAS_RESID_F32_LN needs x16 [M, ldx] and stats_out [M, N/64, 2]");
+    GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
+               a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out};
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SLIME_BF16) return launch_T<BF16>(g, epilogue, s);
-    if (dtype == SLIME_F16) return launch_T<F16>(g, epilogue, s);
-    slime_set_error("gemm: dtype %d is not a 16-bit MFMA type", dtype);
+    if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
+    if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);
+    slime_set_error("gemm: dtype %d is not a 16-bit MFMA type", a->dtype);
     return SLIME_EINVAL;
+}
+
+extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
+                          int M, int N, int K, int dtype, int epilogue, void* stream) {
+    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN, "gemm: BIAS_RESID_F32_LN has extra outputs: use slime_gemm_ex");
+    slime_gemm_args a{};
+    a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.dtype = dtype; a.epilogue = epilogue;
+    return slime_gemm_ex(&a, stream);
 }

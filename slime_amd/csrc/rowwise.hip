@@ -188,13 +188,14 @@ extern "C" int slime_im2col(const void* pixels, int pix_dtype, void* out, int n,
 // ------------------------------------------------------------------------------------------------
 // h[n, 1+P, D] = pre_layrnorm(cat(cls, patch_out) + pos)
 // ------------------------------------------------------------------------------------------------
-template <int VPL>
+template <typename T, int VPL>
 __global__ void __launch_bounds__(256) embed_prenorm_kernel(const float* patch_out, const float* cls, const float* pos,
                                                             const float* w, const float* b, float eps, float* h,
-                                                            int n, int P) {
+                                                            char* x16, float* stats, int n, int P) {
     constexpr int D = 64 * VPL;
     constexpr int VEC = (VPL >= 4) ? 4 : 2;
     constexpr int NV = VPL / VEC;
+    constexpr int LPG = 64 / VEC;                       // lanes that share one 64-column group of a chunk
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long)n * (P + 1)) return;
@@ -222,22 +223,65 @@ __global__ void __launch_bounds__(256) embed_prenorm_kernel(const float* patch_o
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * VEC;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[c + j] = (v[i * VEC + j] - mean) * rstd * w[c + j] + b[c + j];
+        for (int j = 0; j < VEC; ++j) {
+            v[i * VEC + j] = (v[i * VEC + j] - mean) * rstd * w[c + j] + b[c + j];
+            o[c + j] = v[i * VEC + j];
+        }
+    }
+    if (x16) {
+        // first LayerNorm of the layer stack folded into the q/k/v GEMM (slime_gemm_ex): the rows rounded to T and the
+        // (sum, sum of squares) of the rounded values per 64-column group.  Chunk i holds columns 64 VEC i ..: its LPG-lane
+        // groups are the 64-column groups.
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            float sx = 0.f, sq = 0.f;
+            if constexpr (VEC == 4) {
+                u32x2 pk = {T::pack2(v[i * 4], v[i * 4 + 1]), T::pack2(v[i * 4 + 2], v[i * 4 + 3])};
+                *reinterpret_cast<u32x2*>(x16 + ((size_t)row * D + c) * 2) = pk;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { const float lo = T::lo(pk[k]), hi = T::hi(pk[k]); sx += lo; sx += hi; sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq); }
+            } else {
+                const unsigned pk = T::pack2(v[i * 2], v[i * 2 + 1]);
+                *reinterpret_cast<unsigned*>(x16 + ((size_t)row * D + c) * 2) = pk;
+                const float lo = T::lo(pk), hi = T::hi(pk);
+                sx = lo + hi; sq = fmaf(lo, lo, hi * hi);
+            }
+#pragma unroll
+            for (int off = LPG / 2; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sq += __shfl_xor(sq, off); }
+            if ((lane & (LPG - 1)) == 0)
+                *reinterpret_cast<float2*>(stats + ((size_t)row * (D / 64) + (c >> 6)) * 2) = make_float2(sx, sq);
+        }
     }
 }
 
 extern "C" int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
-                                   const float* ln_b, float eps, float* h, int n, int P, int D, void* stream) {
+                                   const float* ln_b, float eps, float* h, void* x16, float* stats, int dtype, int n, int P,
+                                   int D, void* stream) {
     SLIME_REQUIRE(patch_out && cls && pos && ln_w && ln_b && h && n > 0 && P > 0, "embed_prenorm: bad input");
+    SLIME_REQUIRE((x16 == nullptr) == (stats == nullptr), "embed_prenorm: x16 and stats come together");
+    SLIME_REQUIRE(!x16 || dtype == SLIME_BF16 || dtype == SLIME_F16, "embed_prenorm: x16 dtype must be BF16 or F16");
     const long rows = (long)n * (P + 1);
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    switch (D) {
-        case 128: hipLaunchKernelGGL((embed_prenorm_kernel<2>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
-        case 256: hipLaunchKernelGGL((embed_prenorm_kernel<4>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
-        case 1024: hipLaunchKernelGGL((embed_prenorm_kernel<16>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, n, P); break;
-        default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
+    char* x = (char*)x16;
+#define EP_LAUNCH(TT, V) hipLaunchKernelGGL((embed_prenorm_kernel<TT, V>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, x, stats, n, P)
+    if (dtype == SLIME_F16) {
+        switch (D) {
+            case 128: EP_LAUNCH(F16, 2); break;
+            case 256: EP_LAUNCH(F16, 4); break;
+            case 1024: EP_LAUNCH(F16, 16); break;
+            default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
+        }
+    } else {
+        switch (D) {
+            case 128: EP_LAUNCH(BF16, 2); break;
+            case 256: EP_LAUNCH(BF16, 4); break;
+            case 1024: EP_LAUNCH(BF16, 16); break;
+            default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
+        }
     }
+#undef EP_LAUNCH
     SLIME_CHECK_LAUNCH("embed_prenorm");
     return SLIME_OK;
 }

@@ -75,6 +75,34 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogu
     return out
 
 
+def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], h: torch.Tensor):
+    """h (fp32, in place) += a @ w.T + bias; returns (x16 = T(h), stats [M, N/64, 2]): SLIME_EPI_BIAS_RESID_F32_LN."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    x16 = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+    g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(h), ldc=h.stride(0), M=M, N=N, K=K,
+                      dtype=dtype_code(a.dtype), epilogue=_lib.EPI_BIAS_RESID_F32_LN, x16=_ptr(x16), ldx=N, stats_out=_ptr(stats))
+    _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
+    return x16, stats
+
+
+def gemm_ln_consumer(x16: torch.Tensor, stats: torch.Tensor, w_folded: torch.Tensor, bias_folded: torch.Tensor, colsum: torch.Tensor,
+                     eps: float, epilogue: int) -> torch.Tensor:
+    """epi(LayerNorm(x16) @ W.T + b) with the LayerNorm folded: w_folded = T(W diag(gamma)), bias_folded = b + W beta,
+    colsum = row sums of w_folded; stats from the producer.  Output T [M, N]."""
+    lib = _lib.load()
+    M, K = x16.shape
+    N = w_folded.shape[0]
+    out = torch.empty((M, N), dtype=x16.dtype, device=x16.device)
+    g = _lib.GemmArgs(A=_ptr(x16), lda=x16.stride(0), B=_ptr(w_folded), bias=_ptr(bias_folded), C=_ptr(out), ldc=N, M=M, N=N, K=K,
+                      dtype=dtype_code(x16.dtype), epilogue=epilogue, ln_stats=_ptr(stats), ln_groups=stats.shape[1],
+                      ln_colsum=_ptr(colsum), ln_eps=float(eps))
+    _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
+    return out
+
+
 def layernorm(x: torch.Tensor, w, b, eps: float, dtype: torch.dtype, want_f32=False, want_t=True,
               add: Optional[torch.Tensor] = None, normalize=True):
     lib = _lib.load()
@@ -163,25 +191,43 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
 
     if L > 0:
         p = "encoder.layers.{}."
-        T["ln1_w"], T["ln1_b"] = stack(p + "layer_norm1.weight", f32), stack(p + "layer_norm1.bias", f32)
-        T["ln2_w"], T["ln2_b"] = stack(p + "layer_norm2.weight", f32), stack(p + "layer_norm2.bias", f32)
-        wq, bq = [], []
+
+        def fold_ln(Wm, bm, gamma, beta, row_scale=None):
+            """LayerNorm folded into the Linear that consumes it (slime_gemm_ex): W' = W diag(gamma) rounded to T,
+            b' = b + W beta, colsum = row sums of the ROUNDED W' (it must cancel the mean term of what the MFMA multiplies)."""
+            W64 = Wm.detach().double().cpu()
+            Wp = W64 * gamma.detach().double().cpu()[None, :]
+            bp = bm.detach().double().cpu() + W64 @ beta.detach().double().cpu()
+            if row_scale is not None:
+                Wp, bp = Wp * row_scale[:, None], bp * row_scale
+            Wt = Wp.float().to(dtype)
+            return Wt, bp.float(), Wt.double().sum(1).float()
+
+        rs = torch.ones(3 * D, dtype=torch.float64)
+        rs[:D] = scale                                         # q rows carry dh^-0.5 * log2 e (slime_attention contract)
+        wq, bq, cq, w1, b1, c1 = [], [], [], [], [], []
         for i in range(L):
-            q = f"encoder.layers.{i}.self_attn."
-            wq.append(torch.cat([sd[q + "q_proj.weight"].float() * scale, sd[q + "k_proj.weight"].float(),
-                                 sd[q + "v_proj.weight"].float()], 0))
-            bq.append(torch.cat([sd[q + "q_proj.bias"].float() * scale, sd[q + "k_proj.bias"].float(),
-                                 sd[q + "v_proj.bias"].float()], 0))
-        T["w_qkv"] = torch.stack([tt(w) for w in wq]).contiguous()
-        T["b_qkv"] = torch.stack([f32(b) for b in bq]).contiguous()
+            q = f"encoder.layers.{i}."
+            a = q + "self_attn."
+            Wm = torch.cat([sd[a + "q_proj.weight"].float(), sd[a + "k_proj.weight"].float(), sd[a + "v_proj.weight"].float()], 0)
+            bm = torch.cat([sd[a + "q_proj.bias"].float(), sd[a + "k_proj.bias"].float(), sd[a + "v_proj.bias"].float()], 0)
+            Wt, bp, cs = fold_ln(Wm, bm, sd[q + "layer_norm1.weight"], sd[q + "layer_norm1.bias"], rs)
+            wq.append(Wt); bq.append(bp); cq.append(cs)
+            Wt, bp, cs = fold_ln(sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"], sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"])
+            w1.append(Wt); b1.append(bp); c1.append(cs)
+
+        def dev_stack(ts):
+            return torch.stack(ts).to(device).contiguous()
+
+        T["w_qkv"], T["b_qkv"], T["colsum_qkv"] = dev_stack(wq), dev_stack(bq), dev_stack(cq)
+        T["w_fc1"], T["b_fc1"], T["colsum_fc1"] = dev_stack(w1), dev_stack(b1), dev_stack(c1)
         T["w_o"], T["b_o"] = stack(p + "self_attn.out_proj.weight", tt), stack(p + "self_attn.out_proj.bias", f32)
-        T["w_fc1"], T["b_fc1"] = stack(p + "mlp.fc1.weight", tt), stack(p + "mlp.fc1.bias", f32)
         T["w_fc2"], T["b_fc2"] = stack(p + "mlp.fc2.weight", tt), stack(p + "mlp.fc2.bias", f32)
     d = _lib.VitDesc()
     d.hidden, d.inter, d.heads, d.layers_run = D, Fi, cfg.num_attention_heads, L
     d.image, d.patch, d.kpad, d.dtype, d.eps = cfg.image_size, cfg.patch_size, kpad, dtype_code(dtype), cfg.layer_norm_eps
-    for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o",
-                 "ln2_w", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+    for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "w_qkv", "b_qkv", "colsum_qkv", "w_o", "b_o",
+                 "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2"):
         setattr(d, name, T[name].data_ptr() if name in T and T[name] is not None else None)
     return PackedTower(cfg, dtype, L, T, d)
 
@@ -234,10 +280,9 @@ def tower_kernel_names(pt: PackedTower, n_crops: int) -> Dict[int, str]:
     t = "F16" if pt.dtype == torch.float16 else "BF16"
     return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T),
             2: f"attn64r_kernel<{t}>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
-            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32),
             5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T),
-            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32),
-            0: f"layernorm_kernel<{t}, {D // 64}>", 4: f"layernorm_kernel<{t}, {D // 64}>"}
+            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN),
+            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN)}
 
 
 @dataclass

@@ -84,6 +84,62 @@ def test_gemm_production_shapes(dev, dtype, M, N, K):
     _check_all_epilogues(dev, dtype, M, N, K)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 256, 128), (11540, 1024, 4096), (11540, 1024, 1024)])
+def test_gemm_layernorm_fold_producer(dev, dtype, M, N, K):
+    """SLIME_EPI_BIAS_RESID_F32_LN: the residual update of BIAS_RESID_F32 bit for bit, plus x16 = T(h) exactly and the
+    (sum, sum of squares) of the rounded rows per 64-column group (every kernel family via the auto dispatch: 128x128
+    lock-step, ping-pong, and -- at M = 11540, K = 4096 / 1024 -- the production launch shapes of fc2 / out_proj)."""
+    from slime_amd import ops, _lib
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 3)
+    h = _rand((M, N), torch.float32, dev, 4, 2.0) + 0.3
+    h_plain = h.clone()
+    ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h_plain)
+    x16, stats = ops.gemm_ln_producer(a, w, bias, h)
+    assert torch.equal(h, h_plain)
+    assert torch.equal(x16, h.to(dtype))
+    xr = x16.float().view(M, N // 64, 64)
+    assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("epi", ["bias", "quick_gelu"])
+@pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 256, 128), (577, 768, 256), (11540, 3072, 1024), (11540, 4096, 1024)])
+def test_gemm_layernorm_fold_consumer(dev, dtype, epi, M, N, K):
+    """LayerNorm folded into the consuming GEMM vs the unfused fp32 computation on the same rounded operands:
+    epi(LayerNorm(x16; gamma, beta) @ W^T + b) with W' = T(W diag(gamma)), b' = b + W beta, colsum = row sums of W'.
+    Rows carry a mean offset and a few large channels (the case the fold's  acc - mu * colsum  cancellation must survive)."""
+    from slime_amd import ops, _lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.8
+    x[:, 7] += 40.0
+    x[:, K // 2] -= 25.0
+    h = x.to(dev)
+    x16 = h.to(dtype)
+    xr = x16.float().view(M, K // 64, 64)
+    stats = torch.stack([xr.sum(-1), (xr * xr).sum(-1)], -1).contiguous()
+    gamma = (torch.randn(K, generator=g) * 0.2 + 1).to(dev)
+    beta = (torch.randn(K, generator=g) * 0.2).to(dev)
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    Wf = (W.double() * gamma.double()[None]).float().to(dtype)
+    bf = (b.double() + W.double() @ beta.double()).float()
+    colsum = Wf.double().sum(1).float()
+    code = _lib.EPI_BIAS_T if epi == "bias" else _lib.EPI_BIAS_QUICKGELU_T
+    out = ops.gemm_ln_consumer(x16, stats, Wf, bf, colsum, 1e-5, code)
+    xn = F.layer_norm(x16.double(), (K,), None, None, 1e-5)
+    ref = xn @ Wf.double().t() + bf.double()
+    if epi == "quick_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+    assert out.dtype == dtype and rel_l2(out.float(), ref) < TOL_T[dtype]
+    # ... and it equals (to rounding of the A operand) the unfused kernel sequence it replaces
+    _, xn16, _ = ops.layernorm(x16.float(), gamma, beta, 1e-5, dtype)
+    unf = ops.gemm(xn16, W.to(dtype), b, code)
+    assert rel_l2(out.float(), unf.float()) < 3 * TOL_T[dtype]
+
+
 def test_gemm_strided_and_identity(dev):
     """lda/ldc > width (the q/k/v thirds of a packed buffer) and an A = I transpose check."""
     from slime_amd import ops, _lib
@@ -163,9 +219,19 @@ def test_im2col_and_embed(dev):
     b = _rand((D,), torch.float32, dev, 16) * 0.1
     h = torch.empty((n, P + 1, D), dtype=torch.float32, device=dev)
     _lib.check(lib.slime_embed_prenorm(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5,
-                                       h.data_ptr(), n, P, D, st))
+                                       h.data_ptr(), None, None, _lib.BF16, n, P, D, st))
     x = torch.cat([cls.expand(n, 1, D), pe.view(n, P, D)], 1) + pos
     assert rel_l2(h.cpu(), F.layer_norm(x, (D,), w, b, 1e-5).cpu()) < TOL_F32
+    # ... and with the outputs that prepare the first folded LayerNorm: x16 = T(h) exactly, partial sums of the ROUNDED rows
+    for dt, code in ((torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
+        h2 = torch.empty_like(h)
+        x16 = torch.empty((n * (P + 1), D), dtype=dt, device=dev)
+        stats = torch.empty((n * (P + 1), D // 64, 2), dtype=torch.float32, device=dev)
+        _lib.check(lib.slime_embed_prenorm(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5,
+                                           h2.data_ptr(), x16.data_ptr(), stats.data_ptr(), code, n, P, D, st))
+        assert torch.equal(h2, h) and torch.equal(x16, h.view(-1, D).to(dt))
+        xr = x16.float().view(-1, D // 64, 64)
+        assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
 
 
 def test_gate_mix_gather_merge(dev):

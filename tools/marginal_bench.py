@@ -15,8 +15,8 @@ def run():
     for pt, s, p in zip(pts, streams, parts):
         with torch.cuda.stream(s): ops.tower_forward(pt, p)
     for s in streams: cur.wait_stream(s)
-NAMES = {0: "LN1", 1: "qkv", 2: "attention", 3: "out_proj", 4: "LN2", 5: "fc1", 6: "fc2"}
-CASES = [("full", 0)] + [(f"without {n}", 1 << k) for k, n in NAMES.items()] + [("without LN1+LN2", 0b10001), ("GEMMs only", 0b0010101), ("full", 0)]
+NAMES = {1: "qkv", 2: "attention", 3: "out_proj", 5: "fc1", 6: "fc2"}     # (0 / 4 were the LayerNorm launches: folded into the GEMMs)
+CASES = [("full", 0)] + [(f"without {n}", 1 << k) for k, n in NAMES.items()] + [("GEMMs only", 0b0000100), ("full", 0)]
 for _ in range(3): run()
 base = None
 for name, mask in CASES:
