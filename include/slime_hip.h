@@ -66,7 +66,7 @@ int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C
 /* slime_gemm with LayerNorm FOLDED across two GEMMs (HF CLIPEncoderLayer :370-383: LN1 -> q/k/v, LN2 -> fc1), which removes
  * the LayerNorm launches and the fp32 re-read of the residual stream from the tower:
  *   producer (epilogue SLIME_EPI_BIAS_RESID_F32_LN, the out_proj / fc2 GEMM that updates the residual stream C): also writes
- *     x16[M, ldx] = T(C) and stats_out[M, N/64, 2] = (sum, sum of squares) of the ROUNDED row over each 64-column group;
+ *     x16[M, ldx] = T(C) and stats_out[M, N/64, 2] = (sum, sum of squares) of the updated fp32 row over each 64-column group;
  *   consumer (ln_stats != NULL; epilogue BIAS_T or BIAS_QUICKGELU_T): A = x16 (un-normalised), B = W . diag(gamma) rounded to T,
  *     bias = b + W beta, ln_colsum[n] = sum_k B[n, k]; the epilogue evaluates rstd * (acc - mu * ln_colsum[n]) + bias[n] with
  *     mu / rstd = rsqrt(var + ln_eps) from the ln_groups partial sums of each row (K = the normalised width).

@@ -66,7 +66,15 @@ __device__ __forceinline__ void stage_ln_rows(const GemmArgs& g, const int m0, f
         if (row < g.M) {
             const float2* st = reinterpret_cast<const float2*>(g.ln_stats) + (size_t)row * g.ln_groups;
             float sx = 0.f, sq = 0.f;
-            for (int i = 0; i < g.ln_groups; ++i) { const float2 v = st[i]; sx += v.x; sq += v.y; }
+            if (g.ln_groups == 16) {                          // D = 1024: the row's 128 bytes as 8 independent 16-byte loads
+                float4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const float4*>(st)[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sx += v[i].x; sq += v[i].y; sx += v[i].z; sq += v[i].w; }     // group order 0, 1, 2, ...
+            } else {
+                for (int i = 0; i < g.ln_groups; ++i) { const float2 v = st[i]; sx += v.x; sq += v.y; }
+            }
             const float inv = 1.0f / (float)g.K;
             const float mu = sx * inv;
             const float var = fmaxf(sq * inv - mu * mu, 0.f);
@@ -223,8 +231,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                     }
                 }
                 if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
-                    // the next GEMM's A operand: the updated rows rounded to T, and the partial sums of the ROUNDED values
-                    // (what that GEMM multiplies) per 64-column group = lane-local over the pair of 32-column blocks, then
+                    // the next GEMM's A operand: the updated rows rounded to T, and the partial sums of the rows per 64-column group = lane-local over the pair of 32-column blocks, then
                     // across the wave's four 16-lane rows; same order in every kernel of this file
 #pragma unroll
                     for (int pp = 0; pp < NP / 2; ++pp) {
@@ -237,11 +244,13 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                             w[2] = T::pack2(acc[i][2 * p + 1][0], acc[i][2 * p + 1][1]); w[3] = T::pack2(acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]);
                             if (in_range(row))
                                 *reinterpret_cast<u32x4*>(g.x16 + ((size_t)row * g.ldx + col_base + 32 * p) * 2) = w;
+                            // sums of the fp32 values (the rounded ones differ by 2^-9 relative per element with random sign:
+                            // far below what the statistics need, and unpacking them again would double this loop's VALU work)
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
-                                const float lo = T::lo(w[k]), hi = T::hi(w[k]);
-                                sx += lo; sx += hi;
-                                sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq);
+                                const float a0 = acc[i][2 * p][k], a1 = acc[i][2 * p + 1][k];
+                                sx += a0; sx += a1;
+                                sq = fmaf(a0, a0, sq); sq = fmaf(a1, a1, sq);
                             }
                         }
                         sx = rows4_allsum(sx);

@@ -100,7 +100,7 @@ def test_gemm_layernorm_fold_producer(dev, dtype, M, N, K):
     x16, stats = ops.gemm_ln_producer(a, w, bias, h)
     assert torch.equal(h, h_plain)
     assert torch.equal(x16, h.to(dtype))
-    xr = x16.float().view(M, N // 64, 64)
+    xr = h.view(M, N // 64, 64)
     assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
 
 

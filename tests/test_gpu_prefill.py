@@ -98,8 +98,10 @@ def test_rope_kernel_vs_oracle(dev, dtype):
     want[:, :HQ + HKV] = P.apply_rope(x[:, :HQ + HKV], cos, sin)
     want[:, :HQ] *= scale
     d = qkv.to(dev).clone()
-    _lib.check(lib.slime_rope(d.data_ptr(), d.shape[-1], pos.to(torch.int32).to(dev).data_ptr(), B * S, HQ + HKV, HQ, 128,
-                              inv.to(dev).data_ptr(), scale, ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream))
+    pos_d, inv_d = pos.to(torch.int32).to(dev), inv.to(dev)             # keep the device copies alive across the launch
+    _lib.check(lib.slime_rope(d.data_ptr(), d.shape[-1], pos_d.data_ptr(), B * S, HQ + HKV, HQ, 128, inv_d.data_ptr(), scale,
+                              ops.dtype_code(dtype), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
     got = d.float().cpu().view(B, S, HQ + 2 * HKV, 128).transpose(1, 2)
     assert rel_l2(got[:, :HQ + HKV], want[:, :HQ + HKV]) < {torch.bfloat16: 4e-3, torch.float16: 6e-4}[dtype]
     assert torch.equal(got[:, HQ + HKV:], x[:, HQ + HKV:])                       # v untouched

@@ -7,7 +7,7 @@ def load_counters(d):
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if "gemm" in name or "attn" in name or "layernorm" in name:
+            if any(k in name for k in ("gemm", "attn", "layernorm", "embed_prenorm", "rope", "im2col", "gather_rows")):
                 key = name.replace("void ", "").split("(")[0]
                 rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 rows[key]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
