@@ -695,14 +695,20 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             for (int hh = 0; hh < 2; ++hh)
                 vptr[hh] = lds_addr(Vlds) + vrow * RB + (((4 * hh + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4);
         }
-        auto qk = [&](f32x4 (&sc)[NSUB][2]) {
-            u32x4 kf[2][KS];
+        // K fragments are fetched one call ahead: qk() multiplies the fragments the PREVIOUS call (or the prologue) requested and
+        // requests the next step's before it returns, so their LDS latency passes under the softmax / PV work in between instead
+        // of in front of the first QK MFMA (a wave is in-order: an exposed ds_read wait idles its SIMD slot; both waves of a
+        // SIMD hit it at every step).
+        u32x4 kf[2][KS];
+        auto k_request = [&]() {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) kf[t][ks] = t == 0 ? lds_b128_asm<0>(kptr[ks]) : lds_b128_asm<16 * RB>(kptr[ks]);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
+        };
+        auto qk = [&](f32x4 (&sc)[NSUB][2], bool request_next) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -710,6 +716,11 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], ks == 0 ? cinit[s] : sc[s][t]);
+            if (request_next) {
+                // the MFMAs above have READ kf when they issued (in order), but the compiler must not hoist the requests
+                asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
+                k_request();
+            }
         };
         auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], f32x4 (&nxt)[NSUB][2], bool has_next, bool masked) {
             u32x2 v0[DT], v1[DT];
@@ -781,18 +792,22 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
 
         f32x4 sA[NSUB][2], sB[NSUB][2];
         const bool ragged = (a.n_kv & 31) != 0;
+        // step st's K rows must have landed before they are REQUESTED, i.e. one qk() call earlier than they are multiplied
         before_step(0);
-        qk(sA);
+        k_request();                                         // step 0
+        if (steps > 1) before_step(1);
+        qk(sA, steps > 1);                                   // multiplies step 0, requests step 1
         int st = 0;
         for (; st + 2 < steps; st += 2) {
-            qk(sB);                                          // step st+1: same granule as step st
-            softmax_pv(st, sA, sB, true, false);
             before_step(st + 2);
-            qk(sA);
+            qk(sB, true);                                    // multiplies step st+1, requests step st+2
+            softmax_pv(st, sA, sB, true, false);
+            if (st + 3 < steps) before_step(st + 3);
+            qk(sA, st + 3 < steps);                          // multiplies step st+2, requests step st+3
             softmax_pv(st + 1, sB, sA, true, false);
         }
         if (st + 2 == steps) {
-            qk(sB);
+            qk(sB, false);
             softmax_pv(st, sA, sB, true, false);
             softmax_pv(st + 1, sB, sA, false, ragged);
         } else {
@@ -861,9 +876,14 @@ static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
     int qsplit = (total_sb + 39) / 40;                        // <= 3 + 2 sub-blocks per wave, 8 waves
-    // small batches (a single image: 5 crops x 16 heads = 80 workgroups on 256 CUs): two workgroups per (crop, head) fill the
-    // chip -- each stages the panel, but the CUs would idle otherwise (B = 5: 30 -> 17 us)
-    if ((long)a.heads * batch * qsplit * 2 <= num_cus() && total_sb >= 16) qsplit *= 2;
+    // One or two workgroups per (crop, head)?  Two re-stage the K/V panel (a half-size workgroup costs ~0.56 of a full one,
+    // measured) but quantise better: rounds of CUs x cost per workgroup decides.  5 crops: 80 -> 160 workgroups, one round
+    // either way, 30 -> 18 us; 20 crops: 320 = 2 rounds x 1.0 vs 640 = 3 rounds x 0.56; 10 crops: 160 = 1 round, stays.
+    if (total_sb >= 16) {
+        const long cus = num_cus(), items = (long)a.heads * batch * qsplit;
+        const double one = (double)((items + cus - 1) / cus), two = (double)((2 * items + cus - 1) / cus) * 0.56;
+        if (two < one) qsplit *= 2;
+    }
     a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
     hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(512), LDS, stream, a);
     SLIME_CHECK_LAUNCH("attention64r");
