@@ -596,10 +596,12 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
 // waits only for the granule it is about to touch (counted vmcnt + barrier), so the first MFMA starts after 16 KiB, not
 // 80 KiB, and the rest of the panel streams in under the arithmetic.
 // ================================================================================================
-template <typename T, int NSUB, bool RESIDENT>
+template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false>
 __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
-    constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608, NW = 8;
-    constexpr int NG = 10;                                 // 64-row DMA granules (the last one is half empty: rows 576..607)
+    constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608;
+    constexpr int NG = (KC / 8 + NW - 1) / NW;            // DMA granules of NW pieces = 8 NW rows (8 waves: 10 x 64 rows, 12 waves: 7 x 96 rows;
+                                                           // the last one holds 4 real pieces, rows 576..607)
+    constexpr int SPG = NW / 4;                            // 32-row kv steps per granule
     constexpr float RESCALE_TH = 8.0f;
     char* Klds = smem;
     char* Vlds = smem + KC * RB;
@@ -635,7 +637,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             // granule gi = pieces 8 gi .. 8 gi + 7; the last granule has 4 pieces: waves 4..7 repeat them (same bytes to the
             // same place) so that every wave has issued exactly 2 (gi + 1) DMAs after granule gi -- the counted waits below
             int piece = gi * NW + wave;
-            if (piece >= KC / 8) piece -= 4;
+            if (piece >= KC / 8) piece = KC / 8 - 4 + (wave & 3);
             const int row = min(piece * 8 + lrow, a.n_kv - 1);
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
                                              LDS_PTR(Klds + piece * 1024), 16, 0, 0);
@@ -647,16 +649,16 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
     // to every wave's pieces.  Called by every wave of the workgroup for gi = 0, 1, 2, ... in order (uniform control flow).
     auto granule_ready = [&](int gi) {
         if constexpr (!RESIDENT) {
-            switch (gi) {
-                case 0: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-                case 1: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-                case 2: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            switch (NG - 1 - gi) {                          // granules still allowed in flight
+                case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -664,7 +666,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto before_step = [&](int st) { if ((st & 1) == 0) granule_ready(st >> 1); };   // step st reads rows 32 st .. 32 st + 31
+    auto before_step = [&](int st) { if (st % SPG == 0) granule_ready(st / SPG); };   // step st reads rows 32 st .. 32 st + 31
 
     const int steps = (a.n_kv + 31) >> 5;
     if constexpr (NSUB == 0) {
@@ -695,10 +697,10 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             for (int hh = 0; hh < 2; ++hh)
                 vptr[hh] = lds_addr(Vlds) + vrow * RB + (((4 * hh + (li & 3)) ^ (((li >> 3) & 1) << 2)) << 4);
         }
-        // K fragments are fetched one call ahead: qk() multiplies the fragments the PREVIOUS call (or the prologue) requested and
-        // requests the next step's before it returns, so their LDS latency passes under the softmax / PV work in between instead
-        // of in front of the first QK MFMA (a wave is in-order: an exposed ds_read wait idles its SIMD slot; both waves of a
-        // SIMD hit it at every step).
+        // KPF (measured alternative, off): K fragments fetched one call ahead -- qk() multiplies the fragments the PREVIOUS call
+        // requested and requests the next step's before it returns, so their LDS latency passes under the softmax / PV work
+        // instead of in front of the first QK MFMA.  Neutral on the clock (58.3 vs 58.1 us per 20 crops) at +16 live VGPRs,
+        // like the 12-wave variant below: the kernel is not bound by exposed LDS latency.
         u32x4 kf[2][KS];
         auto k_request = [&]() {
 #pragma unroll
@@ -709,6 +711,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
         };
         auto qk = [&](f32x4 (&sc)[NSUB][2], bool request_next) {
+            if constexpr (!KPF) k_request();                  // register-lean form: fetch at the point of use
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -716,7 +719,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int s = 0; s < NSUB; ++s) sc[s][t] = T::mfma16(kf[t][ks], qf[s][ks], ks == 0 ? cinit[s] : sc[s][t]);
-            if (request_next) {
+            if (KPF && request_next) {
                 // the MFMAs above have READ kf when they issued (in order), but the compiler must not hoist the requests
                 asm volatile("" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
                 k_request();
@@ -794,7 +797,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
         const bool ragged = (a.n_kv & 31) != 0;
         // step st's K rows must have landed before they are REQUESTED, i.e. one qk() call earlier than they are multiplied
         before_step(0);
-        k_request();                                         // step 0
+        if constexpr (KPF) k_request();                      // step 0
         if (steps > 1) before_step(1);
         qk(sA, steps > 1);                                   // multiplies step 0, requests step 1
         int st = 0;
@@ -868,6 +871,43 @@ __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
     }
 }
 
+// Twelve-wave variant: three waves per SIMD (<= 2 sub-blocks each, <= 168 VGPRs) instead of two with three sub-blocks.
+// rocprofv3 on attn64r: 36 % of the wave cycles are parked at s_waitcnt / s_barrier and 33 % stalled at issue -- latency, not
+// throughput -- so the third wave per SIMD is there to cover the other two's waits.  24 sub-blocks per workgroup at most,
+// i.e. always two workgroups per CLIP (crop, head); pass 1 only.
+template <typename T>
+__global__ void __launch_bounds__(768) attn64w_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 12;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_sb = (a.n_q + 15) >> 4;
+    const int wg_sb0 = blockIdx.z * a.sb_per_wg;
+    const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);      // <= 2 * NW
+    const int base = nsb / NW, rem = nsb % NW;
+    const int cnt = base + (wave < rem ? 1 : 0);
+    const int sb0 = wg_sb0 + wave * base + min(wave, rem);
+    switch (cnt) {
+        case 0: attn64r_pass<T, 0, false, NW, false>(a, smem, b, h, sb0); break;
+        case 1: attn64r_pass<T, 1, false, NW, false>(a, smem, b, h, sb0); break;
+        default: attn64r_pass<T, 2, false, NW, false>(a, smem, b, h, sb0); break;
+    }
+}
+
+template <typename T>
+static int launch_attn64w(const AttnArgs& a0, int batch, hipStream_t stream) {
+    AttnArgs a = a0;
+    constexpr int LDS = 2 * 608 * 128;
+    auto kern = attn64w_kernel<T>;
+    SLIME_SET_LDS_ONCE(kern, LDS, "attention");
+    const int total_sb = (a.n_q + 15) / 16;
+    const int qsplit = (total_sb + 23) / 24;
+    a.sb_per_wg = (total_sb + qsplit - 1) / qsplit;
+    hipLaunchKernelGGL(kern, dim3(a.heads, batch, qsplit), dim3(768), LDS, stream, a);
+    SLIME_CHECK_LAUNCH("attention64w");
+    return SLIME_OK;
+}
+
 template <typename T>
 static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
@@ -935,6 +975,10 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
         return launch_attn64r<BF16>(a, batch, s);
     }
 #ifdef SLIME_DIAG
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 3 && !g_attn_dbg) {
+        if (dtype == SLIME_F16) return launch_attn64w<F16>(a, batch, s);
+        return launch_attn64w<BF16>(a, batch, s);
+    }
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 2 && !g_attn_dbg) {
         // the round-1 kernel (two workgroups per (crop, head), two DMA halves), kept for A/B
         if (dtype == SLIME_F16) return launch_attn64<F16>(a, batch, s);

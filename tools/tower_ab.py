@@ -22,7 +22,8 @@ def timed(n=8):
     for _ in range(n): run()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 what = sys.argv[1] if len(sys.argv) > 1 else "attn"
-cases = {"attn": [("attn64r", lambda: lib.slime_attention_set_variant(0)), ("attn64 (r1)", lambda: lib.slime_attention_set_variant(2))]}[what]
+cases = {"attn": [("attn64r", lambda: lib.slime_attention_set_variant(0)), ("attn64 (r1)", lambda: lib.slime_attention_set_variant(2)),
+                  ("attn64w 12wave", lambda: lib.slime_attention_set_variant(3))]}[what]
 for _ in range(3): run()
 for rnd in range(4):
     for name, setup in cases:
