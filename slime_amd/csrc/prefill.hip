@@ -17,7 +17,8 @@
 //                            attention above, o_proj GEMM.
 //
 // The attention kernel follows attention.hip's transposed formulation (S^T = K Q^T, O^T = V^T P^T: a lane owns one query
-// column, softmax statistics are lane-local, P never touches LDS) with K/V chunks of 288 rows staged through registers.
+// column, softmax statistics are lane-local, P never touches LDS) with K/V chunks of 192 rows staged through registers
+// (issue early / write late: the next chunk is in flight during the current chunk's arithmetic).
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ splice
@@ -149,7 +150,7 @@ __device__ __forceinline__ u32x2 lds_tr16(const char* p) {
 
 template <typename T>
 __global__ void __launch_bounds__(512) prefill_attn_kernel(PrefillArgs a) {
-    constexpr int DH = 128, RB = 256, CPR = 16, KS = 4, DT = 8, KC = 288, NW = 8, NSUB = 2, NT = NW * 64;
+    constexpr int DH = 128, RB = 256, CPR = 16, KS = 4, DT = 8, KC = 192, NW = 8, NSUB = 2, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Klds = smem;
     char* Vlds = smem + KC * RB;
@@ -209,37 +210,42 @@ __global__ void __launch_bounds__(512) prefill_attn_kernel(PrefillArgs a) {
     const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)kvh * DH) * 2;
 
     const int kv_first = (ks_ >> 5) << 5;                     // 32-aligned first step that holds a token
-    for (int kv0 = kv_first; kv0 < kv_hi; kv0 += KC) {
-        if (kv0 > kv_first) __syncthreads();                  // previous chunk fully consumed
-        {   // stage K and V rows kv0 .. kv0 + KC - 1: global (16 B / lane) -> registers -> swizzled LDS
-            constexpr int TOTAL = KC * CPR, U = 3;
-            for (int base = 0; base < TOTAL; base += NT * U) {
-                u32x4 kk[U], vv[U];
+    // K/V chunk staging, split (issue early / write late): the global loads of chunk c+1 are issued BEFORE the arithmetic of
+    // chunk c and held in registers (9 + 9 x 16 B per lane); they are written to LDS, swizzled, after it.  HBM/L2 latency
+    // passes under the MFMAs instead of in front of them.
+    constexpr int TOTAL = KC * CPR, U = TOTAL / NT;           // 16-byte pieces per chunk per operand, per lane
+    static_assert(TOTAL % NT == 0, "chunk pieces must divide over the threads");
+    u32x4 kk[U], vv[U];
+    auto fetch = [&](int kv0) {
 #pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int idx = base + j * NT + tid;
-                    const int r = idx / CPR, u = idx % CPR, gr = kv0 + r;
-                    kk[j] = u32x4{0u, 0u, 0u, 0u}; vv[j] = u32x4{0u, 0u, 0u, 0u};
-                    if (idx < TOTAL && gr < kv_hi) {
-                        kk[j] = *reinterpret_cast<const u32x4*>(kbase + ((size_t)gr * a.k_rs) * 2 + u * 16);
-                        vv[j] = *reinterpret_cast<const u32x4*>(vbase + ((size_t)gr * a.v_rs) * 2 + u * 16);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int idx = base + j * NT + tid;
-                    if (idx < TOTAL) {
-                        const int r = idx / CPR, u = idx % CPR;
-                        *reinterpret_cast<u32x4*>(Klds + r * RB + ((u ^ (r & (CPR - 1))) << 4)) = kk[j];
-                        const int sw = (r & 1) | (((r >> 1) & 3) << 3);
-                        u32x4 w = vv[j];
-                        if (sw & 1) w = u32x4{vv[j][2], vv[j][3], vv[j][0], vv[j][1]};
-                        *reinterpret_cast<u32x4*>(Vlds + r * RB + ((u ^ (sw >> 1)) << 4)) = w;
-                    }
-                }
+        for (int j = 0; j < U; ++j) {
+            const int idx = j * NT + tid;
+            const int r = idx / CPR, u = idx % CPR, gr = kv0 + r;
+            kk[j] = u32x4{0u, 0u, 0u, 0u}; vv[j] = u32x4{0u, 0u, 0u, 0u};
+            if (gr < kv_hi) {
+                kk[j] = *reinterpret_cast<const u32x4*>(kbase + ((size_t)gr * a.k_rs) * 2 + u * 16);
+                vv[j] = *reinterpret_cast<const u32x4*>(vbase + ((size_t)gr * a.v_rs) * 2 + u * 16);
             }
         }
+    };
+    auto commit = [&]() {                                     // registers -> swizzled LDS images
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int idx = j * NT + tid;
+            const int r = idx / CPR, u = idx % CPR;
+            *reinterpret_cast<u32x4*>(Klds + r * RB + ((u ^ (r & (CPR - 1))) << 4)) = kk[j];
+            const int sw = (r & 1) | (((r >> 1) & 3) << 3);
+            u32x4 w = vv[j];
+            if (sw & 1) w = u32x4{vv[j][2], vv[j][3], vv[j][0], vv[j][1]};
+            *reinterpret_cast<u32x4*>(Vlds + r * RB + ((u ^ (sw >> 1)) << 4)) = w;
+        }
+    };
+    if (kv_first < kv_hi) fetch(kv_first);
+    for (int kv0 = kv_first; kv0 < kv_hi; kv0 += KC) {
+        if (kv0 > kv_first) __syncthreads();                  // previous chunk fully consumed
+        commit();
         __syncthreads();
+        if (kv0 + KC < kv_hi) fetch(kv0 + KC);                // in flight during this chunk's arithmetic
         const int rows = min(KC, kv_hi - kv0);
         const int steps = (rows + 31) >> 5;
         for (int st = 0; st < steps; ++st) {
@@ -343,7 +349,7 @@ extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, cons
     SLIME_REQUIRE((kv_start == nullptr) == (kv_len == nullptr), "prefill_attention: kv_start and kv_len come together");
     PrefillArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs, (char*)o, o_bs, o_rs,
                   kv_start, kv_len, S, group};
-    constexpr int LDS = 2 * 288 * 256;
+    constexpr int LDS = 2 * 192 * 256;
     const int QB = 256 / group, nqb = (S + QB - 1) / QB;
     SLIME_REQUIRE(nqb <= 65535, "prefill_attention: sequence too long");
     hipStream_t s = (hipStream_t)stream;
