@@ -162,7 +162,7 @@ def header_symbols():
 
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j4"]
+    cmd = ["make", "-C", CSRC, f"-j{max(4, min(16, os.cpu_count() or 4))}"]      # product + diagnostic library
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
