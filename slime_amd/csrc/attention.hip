@@ -977,21 +977,8 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
         return launch_attn64r<BF16>(a, batch, s);
     }
 #ifdef SLIME_DIAG
-    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant >= 4 && g_attn_variant <= 14 && dtype == SLIME_BF16) {
-        switch (g_attn_variant) {
-            case 4: return launch_attn32<BF16, 0>(a, batch, 0, s);
-            case 5: return launch_attn32<BF16, 0>(a, batch, 2, s);
-            case 6: return launch_attn32<BF16, 1>(a, batch, 0, s);
-            case 7: return launch_attn32<BF16, 2>(a, batch, 0, s);
-            case 8: return launch_attn32<BF16, 5>(a, batch, 0, s);
-            case 9: return launch_attn32<BF16, 6>(a, batch, 0, s);
-            case 10: return launch_attn32<BF16, 6 + 8>(a, batch, 0, s);
-            case 11: return launch_attn32<BF16, 6 + 16>(a, batch, 0, s);
-            case 12: return launch_attn32<BF16, 7>(a, batch, 0, s);
-            case 13: return launch_attn32<BF16, 7 + 8>(a, batch, 0, s);
-            default: return launch_attn32<BF16, 7 + 16>(a, batch, 0, s);
-        }
-    }
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && (g_attn_variant == 4 || g_attn_variant == 5) && dtype == SLIME_BF16)
+        return launch_attn32<BF16>(a, batch, g_attn_variant == 5 ? 2 : 0, s);
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 3 && !g_attn_dbg) {
         if (dtype == SLIME_F16) return launch_attn64w<F16>(a, batch, s);
         return launch_attn64w<BF16>(a, batch, s);
