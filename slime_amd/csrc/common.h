@@ -81,6 +81,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Pin a wave-uniform pointer into SGPRs (the compiler otherwise folds `uniform + lane offset + uniform` into 64-bit
+// VALU adds and loses the SGPR-base addressing mode of global_load_lds).
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// One LDS-DMA piece in the SGPR-base form (64 lanes x 16 B -> 1 KiB at LDS byte address lds_addr, lane-linear):
+// hipcc materialises a 64-bit VGPR address per piece from the builtin (v_lshl_add_u64 + the vaddr form) inside loops,
+// so the instruction is written out.  M0 = LDS base; one wait state between the M0 write and the load.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const char* sbase, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_byte_addr(const char* p) {
+    return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
+}
+
 // ---- host side error plumbing ------------------------------------------------------------------
 void slime_set_error(const char* fmt, ...);
 

@@ -7,8 +7,8 @@ dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 qkv = torch.randn(B, 577, 3072, device=dev).to(dt); qkv[..., :1024] *= 0.125
 q, k, v = qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:]
-for var in (4, 5):
-    lib.slime_attention_set_variant(var)
+for var, abl in ((4, 0), (4, 1), (5, 0), (5, 1)):
+    lib.slime_attention_set_variant(var); lib.slime_attention_set_ablation(abl)
     for _ in range(3): ops.attention(q, k, v, 16, 64)
     nwg = 16 * B * (2 if var == 5 else 1)
     buf = torch.zeros(nwg * 4 * 32, dtype=torch.int64, device=dev)
@@ -19,10 +19,10 @@ for var in (4, 5):
     t0 = t[:, :, 0:1]
     rel = t - t0
     def col(i): return rel[:, :, i].mean().item(), rel[:, :, i].min().item(), rel[:, :, i].max().item()
-    print(f"variant {var}: {nwg} workgroups; cycles since wave start (mean/min/max over waves)")
+    print(f"variant {var} abl {abl}: {nwg} workgroups; cycles since wave start (mean/min/max over waves)")
     for name, i in (("dma issued", 1), ("granule 0", 3), ("step 0", 4), ("step 17", 21), ("step 18", 22), ("loop+pad", 30), ("stored", 31)):
         m, lo, hi = col(i); print(f"  {name:12s} {m:9.0f} {lo:9.0f} {hi:9.0f}")
     d = (t[:, :, 5:23] - t[:, :, 4:22])
     print("  per-step deltas (mean over waves), steps 1..18:", [int(x) for x in d.mean(dim=(0, 1)).tolist()])
     print("  first-wave start spread over workgroups (cycles):", int((t[:, 0, 0].max() - t[:, 0, 0].min()).item()))
-lib.slime_attention_set_variant(0)
+lib.slime_attention_set_variant(0); lib.slime_attention_set_ablation(0)
