@@ -29,6 +29,7 @@ struct AttnArgs {
     int heads, n_q, n_kv, sb_per_wg;
     unsigned long long* dbg;      // diagnostic: 4 s_memtime stamps per wave (NULL in production)
     int abl;                      // diagnostic timing ablations of attn64 (0 in production): 1 = no softmax VALU, 2 = no MFMA
+    int n_full = 0, split = 1, n_cut = 0;   // attn32: items (crop, head) < n_full are one workgroup each, the n_cut others `split` each
 };
 
 template <int DH> __device__ __forceinline__ int v_swizzle(int row) {
@@ -977,8 +978,8 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
         return launch_attn64r<BF16>(a, batch, s);
     }
 #ifdef SLIME_DIAG
-    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && (g_attn_variant == 4 || g_attn_variant == 5) && dtype == SLIME_BF16)
-        return launch_attn32<BF16>(a, batch, g_attn_variant == 5 ? 2 : 0, s);
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant >= 4 && g_attn_variant <= 6 && dtype == SLIME_BF16)
+        return launch_attn32<BF16>(a, batch, g_attn_variant == 5 ? 2 : g_attn_variant == 6 ? -1 : 0, s);
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 3 && !g_attn_dbg) {
         if (dtype == SLIME_F16) return launch_attn64w<F16>(a, batch, s);
         return launch_attn64w<BF16>(a, batch, s);

@@ -34,7 +34,7 @@ for (B, heads, nq, nkv, gain, spike) in [(2, 2, 577, 577, 1.0, False), (3, 4, 57
     q, k, v = qkv[:, :nq, :E], qkv[:, :nkv, E:2 * E], qkv[:, :nkv, 2 * E:]
     want = ref_attn(q, k, v, heads, 64)
     line = f"B={B} heads={heads} nq={nq} nkv={nkv} gain={gain} spike={spike}:"
-    for var in (0, 4, 5):
+    for var in (0, 4, 6):
         lib.slime_attention_set_variant(var)
         out = ops.attention(q, k, v, heads, 64)
         torch.cuda.synchronize()
@@ -44,11 +44,11 @@ for (B, heads, nq, nkv, gain, spike) in [(2, 2, 577, 577, 1.0, False), (3, 4, 57
     print(line, flush=True)
 lib.slime_attention_set_variant(0)
 print("FAILURES:", bad, flush=True)
-for B in (5, 20, 40):
+for B in (5, 10, 20, 40):
     qkv = torch.randn(B, 577, 3072, device=dev).to(dt); qkv[..., :1024] *= 0.125
     q, k, v = qkv[..., :1024], qkv[..., 1024:2048], qkv[..., 2048:]
     for rnd in range(2):
-        for var in (0, 4, 5):
+        for var in (0, 4, 6):
             lib.slime_attention_set_variant(var)
             t = timeit(lambda: ops.attention(q, k, v, 16, 64))
             print(f"B={B:2d} variant {var}: {t*1e6:7.1f} us {4.0*B*16*577*577*64/t/1e12:6.1f} TF/s", flush=True)
