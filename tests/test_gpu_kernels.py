@@ -313,6 +313,40 @@ def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
     assert rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype] * 1.5   # + P rounded to T before PV
 
 
+@pytest.mark.parametrize("variant", [4, 5, 6])
+@pytest.mark.parametrize("B,heads,nq,nkv,gain", [
+    (2, 2, 577, 577, 1.0),      # CLIP geometry: 19 query blocks -> 5,5,5,4 per wave; ragged last key step (one live key)
+    (3, 4, 577, 577, 12.0),     # logits with std 12: the speculative softmax is thrown away and recomputed many times
+    (1, 1, 577, 321, 1.0),      # shortest panel the kernel takes (11 key steps, ragged)
+    (2, 3, 100, 400, 1.0),      # 4 blocks -> one per wave (the NB = 1 pipeline), half-dead last step
+    (2, 2, 33, 608, 2.0),       # 2 blocks: two idle waves that only take part in the barriers; full panel, no ragged step
+    (1, 2, 640, 576, 1.0),      # 20 blocks -> 5 per wave, even number of key steps
+    (2, 2, 300, 577, 6.0),      # 10 blocks -> 3,3,2,2
+    (17, 16, 577, 577, 1.0),    # 272 (crop, head) items: one round of 256 uncut + 16 cut by query blocks
+])
+def test_attention32_alternative(dev, variant, B, heads, nq, nkv, gain):
+    """The measured alternative of the CLIP attention kernel (one wave per SIMD, 32x32x16 MFMAs, hand-placed softmax stream;
+    DESIGN.md section 6), reachable through the DIAGNOSTIC build's variant hook only: 4 = tail cutting, 5 = every item cut in two,
+    6 = uncut.  Same bar as the product kernel, plus a spiked key (the runaway path late in the sweep)."""
+    from slime_amd import ops, _lib
+    E = heads * 64
+    qkv = _rand((B, max(nq, nkv), 3 * E), torch.bfloat16, dev, 50)
+    qkv[..., :E] *= gain * 0.125 * LOG2E
+    if nkv > 500 and nq > 17:
+        qkv[0, 500, E:2 * E] = (qkv[0, 17, :E].float() * 60.0 / gain).to(torch.bfloat16)
+    q, k, v = qkv[:, :nq, :E], qkv[:, :nkv, E:2 * E], qkv[:, :nkv, 2 * E:]
+    ref = _attn_ref(q, k, v, heads, 64)
+    with _lib.diag() as lib:
+        lib.slime_attention_set_variant(variant)
+        try:
+            out = ops.attention(q, k, v, heads, 64)
+            torch.cuda.synchronize()
+        finally:
+            lib.slime_attention_set_variant(0)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("gain", [4.0, 12.0])
 def test_attention_large_logits(dev, dtype, gain):
