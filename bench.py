@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Contract benchmark: image-crops/sec of the SliME visual hot path (ViT + projector) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3|4]
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Default (= what the driver runs) is BASELINE.json configs[1] ("config 2"): one STEP = one pass of the hot path over
@@ -18,6 +18,11 @@ operands, inputs already resident in HBM:
 --config 4  BASELINE configs[3], one GPU: config 2's encode + the visual-token splice into 8 text sequences + the
             attention sub-layer of all 32 Llama-3-8B layers over the spliced sequences (slime_llama_attn_forward:
             q/k/v GEMM, RoPE, causal GQA attention, o_proj); reports the prefill-attention kernel's own roofline.
+
+--config 5  BASELINE configs[4], the video path: 8 frames x (1+4) crops = 40 ViT forwards, STRONG scaling like config 3 (the
+            frames' crops block partitioned over the ranks, chunked all-gather under the tower), adapter for all frames and the
+            prefill of ONE sequence holding the 8 frames' visual tokens (64 text + 8 x 1152 = 9280 positions; 32 attention
+            sub-layers) replicated on every rank -- the language model is not sharded on this path.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : the dominant kernel of the step, algorithmic FLOPs / live HIP-event duration, against the dense bf16 MFMA peak;
@@ -47,6 +52,7 @@ CONFIGS = {                            # images per step, local crops per image,
     2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
     3: dict(images=4, local=16, grid=(4, 4), scaling="strong"),
     4: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
+    5: dict(images=8, local=4, grid=(2, 2), scaling="strong"),
 }
 
 
@@ -159,7 +165,7 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.config == 4 and world > 1:
-        raise SystemExit("--config 4 is the single-GPU prefill configuration (BASELINE configs[3])")
+        raise SystemExit("--config 4 is the single-GPU prefill configuration (BASELINE configs[3]); the sharded one is --config 5")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     import torch.distributed as dist
@@ -233,7 +239,8 @@ def main():
         # what the adapter needs, the adapter runs for the images this rank owns
         pixels = W.synthetic_pixels(n_step, seed=100).to(dev).to(dt)
         vm = tower.vision_tower
-        my_images = D.image_shard(IMAGES, world, rank)
+        # config 5: every rank needs every frame's tokens for the (replicated) prefill, so the adapter runs for all of them
+        my_images = list(range(IMAGES)) if args.config == 5 else D.image_shard(IMAGES, world, rank)
         lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
 
         def tower_fn(x):
@@ -263,6 +270,8 @@ def main():
     prefill = None
     if args.config == 4:
         prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g)
+    elif args.config == 5:
+        prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g, sequences=1)
 
     def step():
         feats = produce()
@@ -321,7 +330,8 @@ def main():
         traffic, traffic_src = pmc_traffic(roof_kernel["rocprof_name"])
         workload = {2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
                     3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
-                    4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers"}[args.config]
+                    4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers",
+                    5: "video path: 8 frames x (1+4) crops = 40 ViT forwards block-partitioned over the GPUs, all-gather, adapter for all frames, visual-token splice into ONE 9280-position sequence + the attention sub-layer of 32 Llama-3-8B layers (replicated per rank)"}[args.config]
         res = {
             "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid" if args.config != 3 else "image-crops/sec (ViT+projector) at 336px, 1+16 grid",
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -358,9 +368,10 @@ def main():
         dist.destroy_process_group()
 
 
-def build_prefill(enc, dev, dt, images, visual_rows, text_tokens=64, layers=32):
-    """Config 4's second half: embed table + 32 Llama-3-8B attention sub-layers (random init), splice plan for `images`
-    sequences of [text/2, <image>, text/2]; returns a callable (visual tokens [B, rows, 4096] bf16) -> hidden states."""
+def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32, sequences=None):
+    """Second half of configs 4 / 5: embed table + 32 Llama-3-8B attention sub-layers (random init) and the splice plan.
+    Config 4: one sequence per image, [text/2, <image>, text/2].  Config 5 (sequences=1): ONE sequence holding all frames,
+    [text chunk, <image>] x n_images + tail.  Returns a callable (visual tokens [n_images, rows, 4096] bf16) -> hidden states."""
     import numpy as np
     from slime_amd import ops
     from slime_amd.model.llava_arch import splice_plan
@@ -368,9 +379,13 @@ def build_prefill(enc, dev, dt, images, visual_rows, text_tokens=64, layers=32):
     D, HQ, HKV = 4096, 32, 8
     g = torch.Generator().manual_seed(99)
     table = (torch.randn(32000, D, generator=g) * 0.02).to(dt).to(dev)
-    ids = torch.randint(3, 32000, (images, text_tokens + 1), generator=g)
-    ids[:, text_tokens // 2] = IMAGE_TOKEN_INDEX
-    src, _, mask, pos = splice_plan(ids.numpy(), None, None, [visual_rows] * images)
+    images = n_images if sequences is None else sequences                 # batch of the language model
+    per_seq = n_images // images
+    ids = torch.randint(3, 32000, (images, text_tokens + per_seq), generator=g)
+    chunk = text_tokens // (per_seq + 1)
+    for j in range(per_seq):
+        ids[:, (j + 1) * chunk + j] = IMAGE_TOKEN_INDEX
+    src, _, mask, pos = splice_plan(ids.numpy(), None, None, [visual_rows] * n_images)
     S = src.shape[1]
     src_d = torch.from_numpy(src).reshape(-1).to(dev)
     pos_d = torch.from_numpy(pos).to(dev)

@@ -178,3 +178,33 @@ def test_prefill_attention_causality_and_group_mapping(dev):
     alone = run(torch.cat([qkv[1:2, 300:], qkv[1:2, :300]], 1).contiguous(), torch.tensor([0], dtype=torch.int32, device=dev),
                 torch.tensor([S - 300], dtype=torch.int32, device=dev))
     assert rel_l2(ranged[1, 300:].float(), alone[0, :S - 300].float()) < 4e-3      # same math; chunk boundaries differ -> rounding only
+
+
+def test_prefill_attention_video_length(dev):
+    """BASELINE configs[4] (bench.py --config 5): ONE sequence of 64 text + 8 x 1152 visual positions = 9280.  Causal GQA
+    attention at that length against plain fp32 torch (8 query / 2 kv heads keep the reference's 9280 x 9280 score matrices small)."""
+    from slime_amd import ops
+    B, S, HQ, HKV = 1, 9280, 8, 2
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    N = (HQ + 2 * HKV) * 128
+    qkv = (torch.randn(B, S, N, generator=g) * 0.5).to(dt).to(dev)
+    qkv[..., :HQ * 128] *= 128 ** -0.5 * 1.4426950408889634 * 2.0                                # logits with std ~1 (log2 units)
+    lib = ops._lib.load()
+    o = torch.empty((B, S, HQ * 128), dtype=dt, device=dev)
+    ops._lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N,
+                                              qkv.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                              B, HQ, HKV, 128, S, None, None, ops.dtype_code(dt), torch.cuda.current_stream().cuda_stream))
+    q = qkv[0, :, :HQ * 128].float().view(S, HQ, 128).transpose(0, 1) / 1.4426950408889634      # [HQ, S, 128], natural-log units
+    k = qkv[0, :, HQ * 128:(HQ + HKV) * 128].float().view(S, HKV, 128).transpose(0, 1)
+    v = qkv[0, :, (HQ + HKV) * 128:].float().view(S, HKV, 128).transpose(0, 1)
+    causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril()
+    worst = 0.0
+    for h in range(HQ):
+        sc = (q[h] @ k[h // (HQ // HKV)].t()).masked_fill(~causal, float("-inf"))
+        ref = torch.softmax(sc, -1) @ v[h // (HQ // HKV)]
+        got = o[0, :, h * 128:(h + 1) * 128].float()
+        worst = max(worst, float((got - ref).norm() / ref.norm()))
+        rows = ((got - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6))
+        assert float(rows.max()) < 5e-2, "no single position far off"
+    assert worst < 6e-3
