@@ -141,6 +141,7 @@ _DIAG_SIGNATURES = {
     "slime_gemm_set_debug": (None, [c_void_p]),
     "slime_attention_set_debug": (None, [c_void_p]),
     "slime_attention_set_variant": (None, [c_int]),
+    "slime_prefill_set_variant": (None, [c_int]),
     "slime_attention_set_ablation": (None, [c_int]),
 }
 

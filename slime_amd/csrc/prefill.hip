@@ -333,6 +333,15 @@ __global__ void __launch_bounds__(512) prefill_attn_kernel(PrefillArgs a) {
     }
 }
 
+#include "prefill32.inc"
+
+#ifdef SLIME_DIAG
+static int g_prefill_variant = 0;      // 1 = force the eight-wave kernel
+extern "C" void slime_prefill_set_variant(int v) { g_prefill_variant = v; }
+#else
+static constexpr int g_prefill_variant = 0;
+#endif
+
 extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, const void* k, long k_bs, long k_rs, const void* v,
                                        long v_bs, long v_rs, void* o, long o_bs, long o_rs, int batch, int n_heads,
                                        int n_kv_heads, int head_dim, int S, const int32_t* kv_start, const int32_t* kv_len,
@@ -349,10 +358,21 @@ extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, cons
     SLIME_REQUIRE((kv_start == nullptr) == (kv_len == nullptr), "prefill_attention: kv_start and kv_len come together");
     PrefillArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs, (char*)o, o_bs, o_rs,
                   kv_start, kv_len, S, group};
+    hipStream_t s = (hipStream_t)stream;
+    if (group == 4 && dtype == SLIME_BF16 && g_prefill_variant == 0) {
+        // Llama-3 geometry: one wave per SIMD, 32x32x16 MFMAs, K/V ring by LDS-DMA (prefill32.inc)
+        constexpr int LDS32 = 2 * 8 * 32 * 256;
+        const int nqb64 = (S + 63) / 64;
+        SLIME_REQUIRE(nqb64 <= 65535, "prefill_attention: sequence too long");
+        auto kern = prefill32_kernel<BF16>;
+        SLIME_SET_LDS_ONCE(kern, LDS32, "prefill_attention");
+        hipLaunchKernelGGL(kern, dim3(n_kv_heads, batch, nqb64), dim3(256), LDS32, s, a);
+        SLIME_CHECK_LAUNCH("prefill_attention");
+        return SLIME_OK;
+    }
     constexpr int LDS = 2 * 192 * 256;
     const int QB = 256 / group, nqb = (S + QB - 1) / QB;
     SLIME_REQUIRE(nqb <= 65535, "prefill_attention: sequence too long");
-    hipStream_t s = (hipStream_t)stream;
     if (dtype == SLIME_F16) {
         auto kern = prefill_attn_kernel<F16>;
         SLIME_SET_LDS_ONCE(kern, LDS, "prefill_attention");
