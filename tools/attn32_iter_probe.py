@@ -39,6 +39,7 @@ def build(path, name, outdir):
         for m in re.finditer(r'\b([va])(\d+)\b', l): regs.add(f"{m.group(1)}{m.group(2)}")
         for m in re.finditer(r'\bs\[(\d+):(\d+)\]', l):
             for i in range(int(m.group(1)), int(m.group(2)) + 1): regs.add(f"s{i}")
+        for m in re.finditer(r'(?<![\w\[])s(\d+)\b', l): regs.add(f"s{m.group(1)}")
     vregs = sorted(r for r in regs if r[0] == 'v'); aregs = sorted(r for r in regs if r[0] == 'a'); sregs = sorted(r for r in regs if r[0] == 's')
     init = "".join(f"v_mov_b32 {r}, 0x3c003c00\\n\\t" for r in vregs) + "".join(f"v_accvgpr_write_b32 {r}, 0\\n\\t" for r in aregs)
     body = "".join(l.replace('"', '') + "\\n\\t" for l in text)
