@@ -390,9 +390,14 @@ def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32
     src_d = torch.from_numpy(src).reshape(-1).to(dev)
     pos_d = torch.from_numpy(pos).to(dev)
     packs = []
+    # Random init with the usual scaled residual projection (o_proj x (2 L)^-0.5, GPT-2 / Megatron style): there is no RMSNorm on
+    # this path (outside SURVEY section 8), and with plain k^-0.5 weights 32 stacked residual sub-layers blow the hidden state
+    # -- and with it the attention logits -- up to 1e5 and more, a regime no trained model is in (SLIME_BENCH_EXPLODING_LOGITS=1
+    # restores it; tools/prefill_stack_ab.py times both kernels in both regimes).
+    o_scale = 1.0 if os.environ.get("SLIME_BENCH_EXPLODING_LOGITS") == "1" else (2.0 * layers) ** -0.5
     for _ in range(layers):
         w = [torch.randn(n, k, generator=g, dtype=torch.float32) * (k ** -0.5) for n, k in ((HQ * 128, D), (HKV * 128, D), (HKV * 128, D), (D, HQ * 128))]
-        packs.append(ops.pack_llama_attention(w[0], w[1], w[2], w[3], HQ, HKV, dt, dev, 500000.0))
+        packs.append(ops.pack_llama_attention(w[0], w[1], w[2], w[3] * o_scale, HQ, HKV, dt, dev, 500000.0))
     M = images * S
     gf_layer = (2.0 * M * (HQ + 2 * HKV) * 128 * D + 2.0 * M * D * HQ * 128 + 4.0 * images * HQ * (S * (S + 1) / 2) * 128) / 1e9
 
@@ -417,7 +422,7 @@ def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32
         hid = (torch.randn(M, D, device=dev) * 0.3).to(dt)
         out = {}
         for label, name, fn, fl, n_, k_ in (
-                ("prefill_attention", "prefill_attn_kernel<BF16>", attn, 4.0 * images * HQ * (S * (S + 1) / 2) * 128, 0, 0),
+                ("prefill_attention", "prefill32_kernel<BF16>", attn, 4.0 * images * HQ * (S * (S + 1) / 2) * 128, 0, 0),
                 ("llama_qkv_proj", "gemm (q|k|v fused)", lambda: ops.gemm(hid, p.tensors["w_qkv"], None, ops._lib.EPI_BIAS_T), 2.0 * M * N * D, N, D)):
             for _ in range(2):
                 fn()

@@ -208,3 +208,29 @@ def test_prefill_attention_video_length(dev):
         rows = ((got - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6))
         assert float(rows.max()) < 5e-2, "no single position far off"
     assert worst < 6e-3
+
+
+def test_prefill_attention_huge_logits(dev):
+    """Language-model logits are not bounded like CLIP's: after a few dozen random-weight layers they reach 1e5..1e6 (log2 units),
+    where the reference maximum no longer fits a single 16-bit MFMA operand.  One-hot-sharp softmax rows must come out finite and
+    equal to fp64 torch."""
+    from slime_amd import ops
+    B, S, HQ, HKV = 2, 600, 8, 2
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(33)
+    N = (HQ + 2 * HKV) * 128
+    qkv = (torch.randn(B, S, N, generator=g) * 0.5).to(dt).to(dev)
+    qkv[..., :HQ * 128] *= 3000.0                                                                  # logits with std ~ 1.7e4
+    lib = ops._lib.load()
+    o = torch.empty((B, S, HQ * 128), dtype=dt, device=dev)
+    ops._lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N,
+                                              qkv.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                              B, HQ, HKV, 128, S, None, None, ops.dtype_code(dt), torch.cuda.current_stream().cuda_stream))
+    assert torch.isfinite(o.float()).all()
+    q = qkv[..., :HQ * 128].double().view(B, S, HQ, 128).transpose(1, 2) / 1.4426950408889634
+    k = qkv[..., HQ * 128:(HQ + HKV) * 128].double().view(B, S, HKV, 128).transpose(1, 2).repeat_interleave(HQ // HKV, 1)
+    v = qkv[..., (HQ + HKV) * 128:].double().view(B, S, HKV, 128).transpose(1, 2).repeat_interleave(HQ // HKV, 1)
+    causal = torch.ones(S, S, dtype=torch.bool, device=dev).tril()
+    ref = (torch.softmax((q @ k.transpose(-1, -2)).masked_fill(~causal, float("-inf")), -1) @ v).transpose(1, 2).reshape(B, S, HQ * 128)
+    err = float((o.double() - ref).norm() / ref.norm())
+    assert err < 6e-3, err
