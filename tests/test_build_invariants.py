@@ -40,12 +40,12 @@ def _kernel_notes(so_path, tmp_path):
 def test_hand_scheduled_kernels_do_not_spill(which, tmp_path):
     kernels = _kernel_notes(_lib.LIB_PATH if which == "product" else _lib.DIAG_LIB_PATH, tmp_path)
     assert kernels, "no kernels found in the code object"
-    watched = [n for n in kernels if re.search(r"attn32_kernel|attn64r_kernel|gemm_w4_kernel|prefill_attn_kernel", n)]
+    watched = [n for n in kernels if re.search(r"attn32_kernel|prefill32_kernel|attn64r_kernel|gemm_w4_kernel|prefill_attn_kernel", n)]
     if which == "diag":
         assert any("attn32_kernel" in n for n in watched), "the diagnostic library lost the attn32 alternative"
-    assert any("gemm_w4_kernel" in n for n in watched)
+    assert any("gemm_w4_kernel" in n for n in watched) and any("prefill32_kernel" in n for n in watched)
     for n in watched:
-        if "attn32_kernel" in n:
+        if "attn32_kernel" in n or "prefill32_kernel" in n:
             assert kernels[n]["private_segment_fixed_size"] == 0 and kernels[n]["vgpr_spill_count"] == 0, (n, kernels[n])
     spilled = {n: kernels[n]["vgpr_spill_count"] for n in watched if kernels[n]["vgpr_spill_count"] > 40}
     assert not spilled, f"register spills grew: {spilled}"
