@@ -29,4 +29,23 @@ for _ in range(4):
                                            S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128, B, HQ, HKV, 128, S, None, None, _lib.BF16,
                                            torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
+# the video-length sequence of config 5
+B, S = 1, 9280
+qkv = (torch.randn(B, S, N, device=dev) * 0.3).to(dt)
+o = torch.empty((B, S, HQ * 128), dtype=dt, device=dev)
+for _ in range(3):
+    _lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N, qkv.data_ptr() + (HQ + HKV) * 256,
+                                           S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128, B, HQ, HKV, 128, S, None, None, _lib.BF16,
+                                           torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+# the measured alternative of the CLIP attention kernel (diagnostic build), 20 crops
+if os.path.exists(_lib.DIAG_LIB_PATH):
+    with _lib.diag() as dl:
+        x = torch.randn(n, 577, 3072, device=dev).to(dt); x[..., :1024] *= 0.125
+        for var in (4, 6):
+            dl.slime_attention_set_variant(var)
+            for _ in range(4):
+                ops.attention(x[..., :1024], x[..., 1024:2048], x[..., 2048:], 16, 64)
+        dl.slime_attention_set_variant(0)
+    torch.cuda.synchronize()
 print("pmc target done")

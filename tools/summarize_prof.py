@@ -7,8 +7,10 @@ def load_counters(d):
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if any(k in name for k in ("gemm", "attn", "layernorm", "embed_prenorm", "rope", "im2col", "gather_rows")):
+            if any(k in name for k in ("gemm", "attn", "prefill32", "layernorm", "embed_prenorm", "rope", "im2col", "gather_rows")):
                 key = name.replace("void ", "").split("(")[0]
+                if ("prefill32" in key or "attn32" in key) and r.get("Grid_Size"):
+                    key += f" [grid {r['Grid_Size']}]"       # one row per launch shape (8 x 1216 and 1 x 9280; cut and uncut)
                 rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 rows[key]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
                 rows[key]["_vgpr"].append(float(r["VGPR_Count"]) + float(r.get("Accum_VGPR_Count", 0) or 0))
@@ -40,7 +42,24 @@ def main():
             o["hbm_write_bytes"] = round(o["WRITE_SIZE"] * 1024)
     os.makedirs("profiles", exist_ok=True)
     json.dump(out, open(f"profiles/{tag}_pmc_kernels.json", "w"), indent=1, sort_keys=True)
-    print(json.dumps(out, indent=1, sort_keys=True))
+    # derived figures per kernel: MFMA-busy fraction of the chip's SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over
+    # SIMDs; GRBM_GUI_ACTIVE x 128 matches the sum at 100 % on this part), LDS conflict share, where the wave cycles went
+    summ = {}
+    for k, o in out.items():
+        r = {"dur_us": round(o.get("dur_ns", 0) / 1e3, 1)}
+        if "hbm_read_bytes_corrected" in o: r["fabric_read_MB_x2corrected"] = round(o["hbm_read_bytes_corrected"] / 1e6, 1)
+        if "hbm_write_bytes" in o: r["fabric_write_MB"] = round(o["hbm_write_bytes"] / 1e6, 1)
+        r["lds_bank_conflict_frac"] = o.get("lds_bank_conflict_frac")
+        if o.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in o:
+            r["mfma_busy_frac"] = round(o["SQ_VALU_MFMA_BUSY_CYCLES"] / (o["GRBM_GUI_ACTIVE"] * 128.0), 3)
+        if o.get("SQ_WAVE_CYCLES"):
+            w = o["SQ_WAVE_CYCLES"]
+            r["wave_cycles_split"] = {"parked_waitcnt_barrier": round(o.get("SQ_WAIT_ANY", 0) / w, 3),
+                                      "issue_stalled": round(o.get("SQ_WAIT_INST_ANY", 0) / w, 3),
+                                      "issuing": round(o.get("SQ_ACTIVE_INST_ANY", 0) / w, 3)}
+        summ[k] = r
+    json.dump(summ, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+    print(json.dumps(summ, indent=1, sort_keys=True))
 
 if __name__ == "__main__":
     main()
