@@ -267,3 +267,38 @@ def test_prefill_attention_is_deterministic(dev):
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
     assert torch.isfinite(outs[0].float()).all()
+
+
+@pytest.mark.parametrize("S", [1, 5, 33, 64, 65, 127, 193])
+def test_prefill_attention_short_sequences(dev, S):
+    """Sequences shorter than a workgroup's 64 query rows / not a multiple of the 32-key step, with and without a token range."""
+    from slime_amd import ops
+    B, HQ, HKV = 2, 8, 2
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(50 + S)
+    N = (HQ + 2 * HKV) * 128
+    qkv = (torch.randn(B, S, N, generator=g) * 0.5).to(dt).to(dev)
+    qkv[..., :HQ * 128] *= 0.2
+    lib = ops._lib.load()
+    start = torch.tensor([0, min(2, S - 1)], dtype=torch.int32, device=dev)
+    length = torch.tensor([S, max(1, S - 3)], dtype=torch.int32, device=dev)
+    for ranges in (False, True):
+        o = torch.full((B, S, HQ * 128), 7.0, dtype=dt, device=dev)
+        ops._lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N,
+                                                  qkv.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                                  B, HQ, HKV, 128, S, start.data_ptr() if ranges else None,
+                                                  length.data_ptr() if ranges else None, ops.dtype_code(dt),
+                                                  torch.cuda.current_stream().cuda_stream))
+        assert torch.isfinite(o.float()).all()
+        for b in range(B):
+            lo = int(start[b]) if ranges else 0
+            hi = min(S, lo + int(length[b])) if ranges else S
+            q = qkv[b, lo:hi, :HQ * 128].float().view(hi - lo, HQ, 128).transpose(0, 1) / 1.4426950408889634
+            k = qkv[b, lo:hi, HQ * 128:(HQ + HKV) * 128].float().view(hi - lo, HKV, 128).transpose(0, 1).repeat_interleave(HQ // HKV, 0)
+            v = qkv[b, lo:hi, (HQ + HKV) * 128:].float().view(hi - lo, HKV, 128).transpose(0, 1).repeat_interleave(HQ // HKV, 0)
+            causal = torch.ones(hi - lo, hi - lo, dtype=torch.bool, device=dev).tril()
+            ref = (torch.softmax((q @ k.transpose(-1, -2)).masked_fill(~causal, float("-inf")), -1) @ v).transpose(0, 1).reshape(hi - lo, HQ * 128)
+            got = o[b, lo:hi].float()
+            assert float((got - ref).norm() / ref.norm()) < 6e-3
+            if ranges:
+                assert float(o[b, :lo].abs().max() if lo else 0) == 0.0 and float(o[b, hi:].abs().max() if hi < S else 0) == 0.0
