@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 2
+#define SLIME_ABI_VERSION 3
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 
@@ -76,11 +76,21 @@ typedef struct {
     int M, N, K, dtype, epilogue;
     const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;     /* consumer side, or NULL / 0 */
     void* x16; int ldx; float* stats_out;                                             /* producer side, or NULL / 0 */
+    const void* B_frag;          /* optional: B in MFMA-fragment order (slime_gemm_pack_b), or NULL                  */
 } slime_gemm_args;
 int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 
+/* A STATIC B operand (nn.Linear weights: every GEMM of this path) can additionally be handed over in MFMA-fragment order:
+ * out[((t*(K/32) + s)*4 + f)*64 + lane] (16-byte units) = B[64t + 32(f>>1) + 8((lane&15)>>2) + 4(f&1) + (lane&3)][32s + 8(lane>>4) .. +8].
+ * With args.B_frag set (B must still be given: small grids keep the LDS-staged kernels) slime_gemm_ex may run the direct-B
+ * kernel -- B fragments by plain 16-byte loads straight into registers, 128 x 256 tiles, two workgroups per CU -- whose
+ * results are bit-identical to the other kernels' (same k order, same epilogues).  Pack once at weight-load time:
+ * N % 64 == 0, K % 64 == 0, out = slime_gemm_packed_b_bytes(N, K) bytes, out != B.  No reference counterpart (layout only). */
+size_t slime_gemm_packed_b_bytes(int N, int K);
+int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* stream);
+
 /* Name (as rocprofv3 prints it) of the kernel instantiation slime_gemm launches for this shape: host-only query. */
-int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out_host, size_t out_len);
+int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, int has_b_frag, char* out_host, size_t out_len);
 
 /* Row-wise LayerNorm over fp32 rows (statistics in fp32, two-pass variance).
  *   y = (x - mean) * rstd * w + b            (normalize != 0)    or   y = x   (normalize == 0)
@@ -238,6 +248,8 @@ typedef struct {
     const float* b_fc1;                     /* f32 [L, inter] = b + W1 ln2_b                                              */
     const float* colsum_fc1;                /* f32 [L, inter]                                                             */
     const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                                   */
+    /* optional fragment-order copies of the four per-layer weights (slime_gemm_pack_b per layer, same layer stride), or NULL */
+    const void*  w_qkv_frag; const void* w_o_frag; const void* w_fc1_frag; const void* w_fc2_frag;
 } slime_vit_desc;
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
@@ -273,6 +285,7 @@ typedef struct {
     const void*  w_v; const float* b_v;
     const void*  w_o; const float* b_o;
     const float* ln_post_w; const float* ln_post_b;
+    const void*  w_k_frag; const void* w_v_frag; const void* w_o_frag;   /* optional slime_gemm_pack_b copies, or NULL */
 } slime_resampler_desc;
 
 size_t slime_resampler_workspace_bytes(const slime_resampler_desc* d, int n);
@@ -288,6 +301,7 @@ typedef struct {
     int in_dim, hidden, dtype;
     const void* w1; const float* b1;        /* T [hidden, in_dim]                                         */
     const void* w2; const float* b2;        /* T [hidden, hidden]                                         */
+    const void* w1_frag; const void* w2_frag; /* optional slime_gemm_pack_b copies, or NULL                */
 } slime_mlp_desc;
 
 size_t slime_mlp_workspace_bytes(const slime_mlp_desc* d, int rows);
@@ -355,6 +369,7 @@ typedef struct {
     const void*  w_qkv;                     /* T   [(n_heads + 2 n_kv_heads) * head_dim, hidden]: q_proj, k_proj, v_proj rows */
     const void*  w_o;                       /* T   [hidden, n_heads * head_dim]                                               */
     const float* inv_freq;                  /* f32 [head_dim / 2]                                                             */
+    const void*  w_qkv_frag; const void* w_o_frag;   /* optional slime_gemm_pack_b copies, or NULL                                */
 } slime_llama_attn_desc;
 
 size_t slime_llama_attn_workspace_bytes(const slime_llama_attn_desc* d, int batch, int S);
@@ -363,6 +378,16 @@ size_t slime_llama_attn_workspace_bytes(const slime_llama_attn_desc* d, int batc
 int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
                              const int32_t* kv_start, const int32_t* kv_len, int batch, int S, void* out, int out_dtype,
                              void* ws, size_t ws_bytes, void* stream);
+
+/* The same sub-layer with the decoder layer's residual add fused into o_proj's epilogue (HF LlamaDecoderLayer.forward:
+ * hidden_states = residual + self_attn(...); the reference reaches it through the patched LlamaAttention.forward,
+ * llama_flash_attn_monkey_patch.py:16-93):  resid_f32[M, hidden] += o_proj(attention(hidden))  in place (fp32 residual
+ * stream, as in the vision tower), next_hidden T [M, hidden] = T(resid_f32) -- the rows the NEXT layer consumes -- and
+ * next_stats fp32 [M, hidden/64, 2] = (sum, sum of squares) of every updated row per 64-column group (what a folded
+ * RMSNorm / LayerNorm of the next layer needs; may not be NULL).  No torch arithmetic is left between two layers. */
+int slime_llama_attn_forward_resid(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
+                                   const int32_t* kv_start, const int32_t* kv_len, int batch, int S, float* resid_f32,
+                                   void* next_hidden, float* next_stats, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN = range(6)
 
@@ -36,14 +36,15 @@ class VitDesc(C.Structure):
                 ("pre_ln_w", c_void_p), ("pre_ln_b", c_void_p),
                 ("w_qkv", c_void_p), ("b_qkv", c_void_p), ("colsum_qkv", c_void_p),
                 ("w_o", c_void_p), ("b_o", c_void_p),
-                ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("colsum_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p)]
+                ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("colsum_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p),
+                ("w_qkv_frag", c_void_p), ("w_o_frag", c_void_p), ("w_fc1_frag", c_void_p), ("w_fc2_frag", c_void_p)]
 
 
 class GemmArgs(C.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_int),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
-                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p)]
+                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p)]
 
 
 class ResamplerDesc(C.Structure):
@@ -51,17 +52,18 @@ class ResamplerDesc(C.Structure):
                 ("eps", c_float), ("q_proj", c_void_p), ("pos_k", c_void_p),
                 ("ln_kv_w", c_void_p), ("ln_kv_b", c_void_p), ("w_k", c_void_p), ("b_k", c_void_p),
                 ("w_v", c_void_p), ("b_v", c_void_p), ("w_o", c_void_p), ("b_o", c_void_p),
-                ("ln_post_w", c_void_p), ("ln_post_b", c_void_p)]
+                ("ln_post_w", c_void_p), ("ln_post_b", c_void_p),
+                ("w_k_frag", c_void_p), ("w_v_frag", c_void_p), ("w_o_frag", c_void_p)]
 
 
 class MlpDesc(C.Structure):
     _fields_ = [("in_dim", c_int), ("hidden", c_int), ("dtype", c_int),
-                ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p)]
+                ("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("w1_frag", c_void_p), ("w2_frag", c_void_p)]
 
 
 class LlamaAttnDesc(C.Structure):
     _fields_ = [("hidden", c_int), ("n_heads", c_int), ("n_kv_heads", c_int), ("head_dim", c_int), ("dtype", c_int),
-                ("w_qkv", c_void_p), ("w_o", c_void_p), ("inv_freq", c_void_p)]
+                ("w_qkv", c_void_p), ("w_o", c_void_p), ("inv_freq", c_void_p), ("w_qkv_frag", c_void_p), ("w_o_frag", c_void_p)]
 
 
 class Probe(C.Structure):
@@ -73,7 +75,9 @@ _SIGNATURES = {
     "slime_abi_version": (c_int, []),
     "slime_last_error": (C.c_char_p, []),
     "slime_gemm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "slime_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, C.c_char_p, c_size_t]),
+    "slime_gemm_kernel_name": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.c_char_p, c_size_t]),
+    "slime_gemm_packed_b_bytes": (c_size_t, [c_int, c_int]),
+    "slime_gemm_pack_b": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "slime_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "slime_im2col": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -128,6 +132,8 @@ _SIGNATURES = {
     "slime_llama_attn_workspace_bytes": (c_size_t, [_P(LlamaAttnDesc), c_int, c_int]),
     "slime_llama_attn_forward": (c_int, [_P(LlamaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_size_t, c_void_p]),
+    "slime_llama_attn_forward_resid": (c_int, [_P(LlamaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 # diagnostic build only (libslime_hip_diag.so): process-global hooks, never exported by the product library
@@ -136,6 +142,7 @@ _DIAG_SIGNATURES = {
     "slime_gemm_set_sched": (None, [c_int]),
     "slime_gemm_set_ablation": (None, [c_int]),
     "slime_gemm_set_group_m": (None, [c_int]),
+    "slime_gemm_set_db_ablation": (None, [c_int]),
     "slime_vit_set_skip_mask": (None, [c_int]),
     "slime_gemm_set_shape_tile": (None, [c_int, c_int, c_int]),
     "slime_gemm_set_debug": (None, [c_void_p]),

@@ -16,6 +16,15 @@ void slime_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* slime_last_error(void) { return g_err; }
+// slime_gemm with the optional fragment-order copy of the static operand
+static int gemm_w(const void* A, int lda, const void* B, const void* B_frag, const float* bias, void* C, int ldc, int M, int N, int K,
+                  int dtype, int epilogue, void* stream) {
+    slime_gemm_args a{};
+    a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.dtype = dtype; a.epilogue = epilogue;
+    a.B_frag = B_frag;
+    return slime_gemm_ex(&a, stream);
+}
+
 extern "C" int slime_abi_version(void) { return SLIME_ABI_VERSION; }
 
 #define TRY(call)                     \
@@ -141,11 +150,15 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
         const char* w_fc1 = (const char*)d->w_fc1 + (size_t)l * F * D * 2;
         const char* w_fc2 = (const char*)d->w_fc2 + (size_t)l * D * F * 2;
         const bool last = l + 1 == d->layers_run;
+        auto frag = [&](const void* base, size_t per_layer) -> const void* {     // fragment-order copy of this layer's weight, if packed
+            return base ? (const char*)base + (size_t)l * per_layer * 2 : nullptr;
+        };
         slime_gemm_args ga{};
         ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
         // q/k/v = LN1(h) Wqkv^T + b  (HF :370-371, :309-311)
         ga.A = xn; ga.lda = D; ga.B = w_qkv; ga.bias = d->b_qkv + (size_t)l * 3 * D; ga.C = qkv; ga.ldc = 3 * D; ga.N = 3 * D; ga.K = D;
         ga.epilogue = SLIME_EPI_BIAS_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_qkv + (size_t)l * 3 * D;
+        ga.B_frag = frag(d->w_qkv_frag, (size_t)3 * D * D);
         PROBED(1, slime_gemm_ex(&ga, stream));
         PROBED(2, slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
                                   qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
@@ -155,12 +168,14 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
         ga.M = M; ga.dtype = dt;
         ga.A = ctx; ga.lda = D; ga.B = w_o; ga.bias = d->b_o + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = D;
         ga.epilogue = SLIME_EPI_BIAS_RESID_F32_LN; ga.x16 = xn; ga.ldx = D; ga.stats_out = stats;
+        ga.B_frag = frag(d->w_o_frag, (size_t)D * D);
         PROBED(3, slime_gemm_ex(&ga, stream));
         // ff = quick_gelu(LN2(h) W1^T + b)  (HF :379-380, :346-350)
         ga = slime_gemm_args{};
         ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
         ga.A = xn; ga.lda = D; ga.B = w_fc1; ga.bias = d->b_fc1 + (size_t)l * F; ga.C = ff; ga.ldc = F; ga.N = F; ga.K = D;
         ga.epilogue = SLIME_EPI_BIAS_QUICKGELU_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_fc1 + (size_t)l * F;
+        ga.B_frag = frag(d->w_fc1_frag, (size_t)F * D);
         PROBED(5, slime_gemm_ex(&ga, stream));
         // h += ff W2^T + b; prepares the next layer's LN1 unless this is the last layer that runs  (HF :381-383)
         ga = slime_gemm_args{};
@@ -168,6 +183,7 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
         ga.A = ff; ga.lda = F; ga.B = w_fc2; ga.bias = d->b_fc2 + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = F;
         ga.epilogue = last ? SLIME_EPI_BIAS_RESID_F32 : SLIME_EPI_BIAS_RESID_F32_LN;
         if (!last) { ga.x16 = xn; ga.ldx = D; ga.stats_out = stats; }
+        ga.B_frag = frag(d->w_fc2_frag, (size_t)D * F);
         PROBED(6, slime_gemm_ex(&ga, stream));
     }
     if (out) {
@@ -225,11 +241,11 @@ extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const floa
     // x = ln_kv(x); K input = x + pos (sampler.py:158,164); V input = x
     TRY(slime_layernorm(x, ldx, Rk, D, d->ln_kv_w, d->ln_kv_b, d->eps, 1, nullptr, w + p.xn, w + p.xk, d->pos_k,
                         d->n_kv, dt, stream));
-    TRY(slime_gemm(w + p.xk, D, d->w_k, d->b_k, w + p.kp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
-    TRY(slime_gemm(w + p.xn, D, d->w_v, d->b_v, w + p.vp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
+    TRY(gemm_w(w + p.xk, D, d->w_k, d->w_k_frag, d->b_k, w + p.kp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
+    TRY(gemm_w(w + p.xn, D, d->w_v, d->w_v_frag, d->b_v, w + p.vp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
     TRY(slime_attention(d->q_proj, 0, D, w + p.kp, (long)d->n_kv * D, D, w + p.vp, (long)d->n_kv * D, D, w + p.ctx,
                         (long)d->n_query * D, D, n, d->heads, dh, d->n_query, d->n_kv, dt, stream));
-    TRY(slime_gemm(w + p.ctx, D, d->w_o, d->b_o, w + p.o32, D, Rq, D, D, dt, SLIME_EPI_BIAS_F32, stream));
+    TRY(gemm_w(w + p.ctx, D, d->w_o, d->w_o_frag, d->b_o, w + p.o32, D, Rq, D, D, dt, SLIME_EPI_BIAS_F32, stream));
     TRY(slime_layernorm((const float*)(w + p.o32), D, Rq, D, d->ln_post_w, d->ln_post_b, d->eps, 1, out_f32, out_t,
                         nullptr, nullptr, 0, dt, stream));
     return SLIME_OK;
@@ -279,9 +295,9 @@ extern "C" int slime_mlp_forward(const slime_mlp_desc* d, const float* x_f32, co
                             nullptr, 0, d->dtype, stream));
         a = w + p.xt;
     }
-    TRY(slime_gemm(a, d->in_dim, d->w1, d->b1, w + p.mid, d->hidden, rows, d->hidden, d->in_dim, d->dtype,
+    TRY(gemm_w(a, d->in_dim, d->w1, d->w1_frag, d->b1, w + p.mid, d->hidden, rows, d->hidden, d->in_dim, d->dtype,
                    SLIME_EPI_BIAS_GELU_T, stream));
-    TRY(slime_gemm(w + p.mid, d->hidden, d->w2, d->b2, out, d->hidden, rows, d->hidden, d->hidden, d->dtype,
+    TRY(gemm_w(w + p.mid, d->hidden, d->w2, d->w2_frag, d->b2, out, d->hidden, rows, d->hidden, d->hidden, d->dtype,
                    SLIME_EPI_BIAS_F32, stream));
     return SLIME_OK;
 }

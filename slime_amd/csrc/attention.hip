@@ -969,6 +969,7 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
                   q_bs % 8 == 0 && k_bs % 8 == 0 && v_bs % 8 == 0 && o_bs % 8 == 0, "attention: strides must be multiples of 8 elements");
     SLIME_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "attention: pointers must be 16-byte aligned");
     SLIME_REQUIRE(batch <= 65535, "attention: batch %d exceeds grid.y", batch);
+    SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "attention: dtype %d is not a 16-bit MFMA type", dtype);
     AttnArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs,
                (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg, g_attn_abl};
     hipStream_t s = (hipStream_t)stream;

@@ -41,6 +41,11 @@ struct GemmArgs {
     const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;
     // producer side (epilogue BIAS_RESID_F32_LN): 16-bit copy of the updated residual rows and their partial sums
     char* x16; int ldx; float* stats_out;
+    // B in MFMA-fragment order (slime_gemm_pack_b), or NULL: lets the dispatch pick gemm_db_kernel
+    const char* Bf;
+    // gemm_db_kernel timing ablations (diagnostic build; wrong results): 1 = every tile's epilogue writes rows 0..127 (the stores
+    // stay in L2: no HBM write burst), 2 = no epilogue at all
+    int db_abl;
 };
 
 // Sum over the four 16-lane rows of a wave (lanes l, l+16, l+32, l+48), result in every row: pure VALU (permlane swaps).
@@ -863,6 +868,203 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 }
 
 
+// ================================================================================================
+// Direct-B kernel (round 3): 128 x 256 x 64 tile, FOUR waves side by side along N (128 x 64 per wave, 128 accumulator
+// registers), TWO workgroups per CU (two waves per SIMD) -- the static operand never touches LDS.
+//
+// Why (tools/gemm_bdirect_probe.hip, main loops only, random operands, M = 11520): the weights are static, so slime_gemm_pack_b
+// lays them out ONCE in MFMA-fragment order -- [N/64][K/32][4 fragments][64 lanes][16 B], rows permuted exactly as the other
+// kernels permute them while staging -- and a wave fetches its fragments with plain global_load_dwordx4 (1 KiB, fully
+// coalesced, L2 resident).  Doing only that at the stream kernel's geometry (256 x 256, one wave per SIMD) is worth 0-3 %:
+// 8 LDS-DMA + 16 ds_read_b128 are traded for 16 register loads that cost the in-order stream about as much.  What the layout
+// buys is the OTHER geometry: with B out of LDS a workgroup needs 32 KiB (A only) and a wave 128 accumulators + 80 fragment
+// registers, so two workgroups share a CU -- and they are independent: the prologue (cold first DMA) and the epilogue (bias /
+// GELU / LayerNorm-fold VALU + the store burst, 15-20 % of a K = 1024 workgroup) of one run under the MFMAs of the other,
+// which the 512-register stream kernel can never do.  LDS traffic per MFMA halves (8 waves x 16 ds_read_b128 per k-tile, 32 KiB
+// of DMA writes per CU); L2 -> CU traffic rises 1.5x (A 16 KiB + B 32 KiB per workgroup k-tile).  Probe: fc1 1226 -> 1339,
+// qkv 1055 -> 1257 TF/s (K = 1024); at K = 4096 the two-workgroup form trails (fc2 1278 -> 1182, N = K = 4096 1524 -> 1462).
+//
+// Stream of one wave, per k-step (32 MFMAs, weight fragment nj outer / activation fragment mi inner):
+//   * weight fragment nj lives in 4 VGPRs for its 8 MFMAs and is re-requested for the NEXT k-step right behind the last of
+//     them (rolling single buffer; the request is in flight for 24 MFMAs ~ 800 cycles); the loads are inline asm with "+v"
+//     destinations (hipcc would otherwise drain every LDS-DMA in front of their first use) and hand-counted vmcnt waits;
+//   * activation fragments are double buffered from LDS (ordinary loads, the compiler counts lgkmcnt), one read per 4 MFMAs;
+//   * k-step 1 of a tile also issues the wave's 4 LDS-DMA pieces of the tile after next; ONE barrier per k-tile.
+// VMEM order inside a k-step: D_j behind MFMA 8 j + 3, G_nj behind MFMA 8 nj + 7.
+// Epilogues, LayerNorm fold, tile order and output layout are those of the other kernels (run_epilogue<T, EPI, 8, 4>).
+// ================================================================================================
+template <int OFF>
+__device__ __forceinline__ void gload16_frag(u32x4& d, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_frag(u32x4& d) {       // the consumer side of gload16_frag: names the register, pins the order
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// VMEM requests younger than weight request G_nj of the PREVIOUS k-step at the moment MFMA group nj of the current one starts
+constexpr int db_younger(int nj, bool prev_dma, bool cur_dma, bool cur_gl) {
+    int c = (3 - nj) + (cur_gl ? nj : 0);
+    for (int j = 0; j < 4; ++j) {
+        const int pos = 8 * j + 3;
+        if (prev_dma && pos > 8 * nj + 7) ++c;
+        if (cur_dma && pos < 8 * nj) ++c;
+    }
+    return c;
+}
+
+template <typename T, int EPI, int KTAG>
+__global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
+    constexpr int MI = 8, NJ = 4, BM = 128, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int nblk = tiles_m * tiles_n;
+    int pid;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 8;
+    const int in_group = GROUP_M * tiles_n;
+    const int first_m = (pid / in_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % in_group) % gsz;
+    const int tn = (pid % in_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's 64-column slice
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    const int li = lane & 15, lq = lane >> 4;
+
+    unsigned soff[AP];
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        const int rl = min(row, g.M - 1 - m0);                       // clamp: rows past M re-read the last row
+        soff[j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
+    }
+    const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem));
+    auto dma = [&](int j, int tile) {
+        lds_dma16(soff[j], uniform_ptr(a_gbase + (size_t)tile * (BK * 2)), lds0 + (tile & 1) * A_BYTES + (wave + 4 * j) * 1024);
+    };
+    // this wave's weight stream: 4 KiB per k-step, contiguous over k-steps
+    const char* bw = uniform_ptr(g.Bf + ((size_t)(n0 / 64 + wave) * (size_t)(g.K / 32)) * 4096);
+    const unsigned boff = lane * 16;
+    u32x4 FB[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) FB[j] = u32x4{0u, 0u, 0u, 0u};
+    auto gl = [&](auto jc, int kstep) {
+        constexpr int j = decltype(jc)::value;
+        gload16_frag<j * 1024>(FB[j], boff, uniform_ptr(bw + (size_t)kstep * 4096));
+    };
+
+    int xb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xb[ks] = li * 128 + (((ks * 4 + lq) ^ (lane & 7)) << 4);
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float* lnrow = reinterpret_cast<float*>(smem + 2 * A_BYTES);
+    const int nk = g.K / BK;
+    stage_ln_rows<BM, 256>(g, m0, lnrow);
+    // ---- prologue: tiles 0 and 1 of A, the weight fragments of k-step 0; drained completely (the counted waits of the
+    // main loop are written for its steady state and are merely conservative on top of an empty queue) ----
+#pragma unroll
+    for (int j = 0; j < AP; ++j) dma(j, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int j = 0; j < AP; ++j) dma(j, 1);
+    }
+    static_for<0, NJ>([&](auto jc) { gl(jc, 0); });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+
+    u32x4 FA[2][MI];
+    auto read_frag = [&](u32x4& dstF, int i, int xbase) { dstF = *reinterpret_cast<const u32x4*>(smem + xbase + i * 2048); };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    // One k-step.  prev_dma / dmas: the previous / this k-step carries the 4 refill pieces; gls: request the weight fragments of
+    // `next_kstep`; reads: fetch the activation fragments of the next k-step from xbase_next.
+    auto kstep = [&](u32x4 (&cur)[MI], u32x4 (&nxt)[MI], auto prev_dma, auto dmas, int dma_tile, auto gls, int next_kstep, auto reads, int xbase_next) {
+        constexpr bool PD = decltype(prev_dma)::value, D = decltype(dmas)::value, G = decltype(gls)::value, R = decltype(reads)::value;
+        static_for<0, NJ>([&](auto njc) {
+            constexpr int nj = decltype(njc)::value;
+            vm_wait_frag<db_younger(nj, PD, D, G)>(FB[nj]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = MI * nj + mi;
+                T::mfma16_agpr(acc[mi][nj], FB[nj], cur[mi]);
+                if constexpr (R) { if (m % 4 == 1) read_frag(nxt[m / 4], m / 4, xbase_next); }
+                if constexpr (D) { if (m % 8 == 3) dma(m / 8, dma_tile); }
+                if constexpr (G) { if (mi == MI - 1) gl(njc, next_kstep); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    auto tile_body = [&](int t, auto prev_dma, auto more, auto refill) {
+        const int so = (t & 1) * A_BYTES, sn = ((t + 1) & 1) * A_BYTES;
+        kstep(FA[0], FA[1], prev_dma, No{}, 0, Yes{}, 2 * t + 1, Yes{}, xb[1] + so);
+        if constexpr (decltype(more)::value) {
+            // tile t+1 has landed (only this k-step's 4 weight requests are younger than its pieces); every read of tile t has returned
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        kstep(FA[1], FA[0], No{}, refill, t + 2, more, 2 * t + 2, more, xb[0] + sn);
+    };
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i) read_frag(FA[0][i], i, xb[0]);
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile_body(t, Yes{}, Yes{}, Yes{});
+    if (t + 1 < nk) { tile_body(t, Yes{}, Yes{}, No{}); ++t; }
+    tile_body(t, No{}, No{}, No{});
+
+    // hand-written MFMAs: pad the matrix pipe's write-back latency and tie every accumulator behind the padding (see gemm_w4_kernel)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+#ifdef SLIME_DIAG
+    if (g.db_abl & 2) return;
+    if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; }
+#endif
+    run_epilogue<T, EPI, MI, NJ>(g, acc, m0 + li, n0 + wave * 64 + 8 * lq, m0 + BM <= g.M, lnrow + 2 * li);
+}
+
+// Static-operand layout of gemm_db_kernel: out[((t * (K/32) + s) * 4 + nj) * 64 + lane] (16-byte units) =
+// B[64 t + 32 (nj >> 1) + 8 ((lane & 15) >> 2) + 4 (nj & 1) + (lane & 3)][32 s + 8 (lane >> 4) .. + 8]  -- the MFMA B-operand
+// fragment (column lane & 15, k group lane >> 4) of the column tile whose rows are permuted so that a lane's results of
+// fragments 2p, 2p+1 are 8 consecutive output columns (the permutation the LDS kernels apply while staging).
+__global__ void __launch_bounds__(256) pack_b_frag_kernel(const u32x4* __restrict__ B, u32x4* __restrict__ out, int N, int K) {
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)N * K / 8;
+    if (o >= total) return;
+    const int lane = (int)(o & 63), nj = (int)((o >> 6) & 3);
+    const size_t ts = o >> 8;
+    const int ksteps = K / 32;
+    const int s = (int)(ts % ksteps), t = (int)(ts / ksteps);
+    const int r = lane & 15;
+    const int n = 64 * t + 32 * (nj >> 1) + 8 * (r >> 2) + 4 * (nj & 1) + (r & 3);
+    out[o] = B[((size_t)n * K + 32 * s + 8 * (lane >> 4)) / 8];
+}
+
 #ifdef SLIME_DIAG   // measured alternatives: compiled into libslime_hip_diag.so only
 // ================================================================================================
 // Persistent ping-pong kernel: the ping-pong kernel above, but a workgroup walks its output tiles
@@ -1356,7 +1558,10 @@ static unsigned long long* g_dbg = nullptr;
 extern "C" void slime_gemm_set_debug(void* p) { g_dbg = (unsigned long long*)p; }
 extern "C" void slime_gemm_set_ablation(int a) { g_ablation = a; }
 extern "C" void slime_gemm_set_group_m(int s) { g_group_m = s; }
+static int g_db_abl = 0;
+extern "C" void slime_gemm_set_db_ablation(int a) { g_db_abl = a; }
 #else
+static constexpr int g_db_abl = 0;
 static constexpr int g_group_m = 0;
 static constexpr unsigned long long* g_dbg = nullptr;
 #endif
@@ -1421,6 +1626,20 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 
+template <typename T, int EPI, int KTAG>
+static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
+    constexpr int LDS = 2 * 128 * 64 * 2 + 128 * 8;                 // two A stages + the LayerNorm-fold row table
+    auto kern = gemm_db_kernel<T, EPI, KTAG>;
+    const int tiles_m = (g.M + 127) / 128, tiles_n = g.N / 256;
+    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
+    SLIME_CHECK_LAUNCH("gemm_db");
+    return SLIME_OK;
+}
+template <typename T, int EPI>
+static int launch_db(const GemmArgs& g, hipStream_t stream) {
+    return g.K >= 2048 ? launch_db_k<T, EPI, 1>(g, stream) : launch_db_k<T, EPI, 0>(g, stream);
+}
+
 template <typename T, int EPI>
 static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0, 3>(g, stream) : launch_pp_k<T, EPI, 0, 0, 3>(g, stream);
@@ -1442,7 +1661,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // throughput kernels; 128x128 (4 waves, 64 KiB LDS, 2 WG/CU) covers narrow N (tiny geometries) and small M.  Partial last
 // rounds of workgroups are filled by running two half batches on two streams (see HipCLIPVisionModel.encode), not by
 // shrinking the tile.  Tile ids: 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 =
-// 192x256 / 256x256 four-wave stream kernel; diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
+// 192x256 / 256x256 four-wave stream kernel, 12 = 128x256 direct-B kernel (needs Bf); diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
 static int auto_tile(const GemmArgs& g) {
     int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
     if (tile == 4) {
@@ -1462,6 +1681,11 @@ static int auto_tile(const GemmArgs& g) {
         // ... and grids that would leave more than half of the CUs without a 256-row workgroup (single images, the adapter's
         // 4608-row projections) take the 128x128 tile: 4x the workgroups, two per CU (M = 4608, N = K = 1024: 29 -> 16.5 us)
         else if (n256 < cus / 2) tile = 3;
+        // ... and when the caller supplies the static operand in fragment order, multi-round grids and every K <= 2048 grid run
+        // the direct-B kernel (128 x 256 tiles, two workgroups per CU).  Same-box A/B (tools/db_tower_bench.py): stand-alone it
+        // wins everywhere but on sub-round K = 4096 grids (fc2 at 11540 rows: 184 tiles, 0.96-1.0x), most at small batches
+        // (2885 rows: fc1 669 -> 857, qkv 564 -> 649 TF/s); the two-stream tower is 2.5-3 % faster with qkv / out_proj / fc1 on it.
+        if (tile != 3 && g.Bf && (n256 >= cus || g.K <= 2048)) tile = 12;
     }
     return tile;
 }
@@ -1491,6 +1715,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
+    if (tile == 12 && !g.Bf) tile = 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && EPI == SLIME_EPI_BIAS_RESID_F32_LN) tile = 4;     // the 32x32 variant has no LayerNorm-fold epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
@@ -1501,6 +1726,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
     if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
 #endif
+    if (tile == 12) return launch_db<T, EPI>(g, stream);
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
     if (tile == 11) return launch_w4<T, EPI, 8>(g, stream);
@@ -1523,13 +1749,15 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
 
 // Name of the kernel instantiation slime_gemm dispatches to for a shape, as rocprofv3 prints it (bench.py labels its per-kernel
 // figures with it, so the bench line and the profiler summary name the same symbol).
-extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, char* out, size_t out_len) {
+extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, int b_frag, char* out, size_t out_len) {
     SLIME_REQUIRE(out && out_len > 0 && M > 0 && N > 0 && K > 0, "gemm_kernel_name: bad input");
-    GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr};
+    GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr,
+               b_frag ? "" : nullptr, 0};
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
-    if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
+    if (tile == 12) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d>", t, epilogue, ktag);
+    else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
     else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, 1>", t, epilogue);
     return SLIME_OK;
@@ -1548,19 +1776,36 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     if (a->ln_stats) {
         SLIME_REQUIRE(a->epilogue == SLIME_EPI_BIAS_T || a->epilogue == SLIME_EPI_BIAS_QUICKGELU_T,
                       "gemm: the LayerNorm fold is built for the BIAS_T / BIAS_QUICKGELU_T epilogues");
-        SLIME_REQUIRE(a->ln_colsum && a->ln_groups > 0 && ((uintptr_t)a->ln_colsum % 16) == 0 && ((uintptr_t)a->ln_stats % 8) == 0,
-                      "gemm: LayerNorm fold needs ln_colsum [N] and ln_groups partial sums per row");
+        SLIME_REQUIRE(a->ln_colsum && a->ln_groups > 0 && ((uintptr_t)a->ln_colsum % 16) == 0 && ((uintptr_t)a->ln_stats % 16) == 0,
+                      "gemm: LayerNorm fold needs ln_colsum [N] and ln_groups partial sums per row (16-byte aligned)");
+        SLIME_REQUIRE(a->ln_groups * 64 == K, "gemm: LayerNorm fold: ln_groups=%d partial sums of 64 columns must cover K=%d", a->ln_groups, K);
     }
     if (a->epilogue == SLIME_EPI_BIAS_RESID_F32_LN)
         SLIME_REQUIRE(a->x16 && a->stats_out && a->ldx >= N && a->ldx % 8 == 0 && ((uintptr_t)a->x16 % 16) == 0 &&
                       ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0, "gemm: BIAS_RESID_F32_LN needs x16 [M, ldx] and stats_out [M, N/64, 2]");
+    // the fragment-order copy of B is optional; it is only usable with whole 64-column tiles, >= 2 k-steps per tile and 32-bit A offsets
+    const bool frag_ok = a->B_frag && N % 256 == 0 && ((uintptr_t)a->B_frag % 16) == 0 && (size_t)128 * lda * 2 < (1ull << 32);
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
-               a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out};
+               a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
+               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);
     slime_set_error("gemm: dtype %d is not a 16-bit MFMA type", a->dtype);
     return SLIME_EINVAL;
+}
+
+extern "C" size_t slime_gemm_packed_b_bytes(int N, int K) { return (N > 0 && K > 0) ? (size_t)N * K * 2 : 0; }
+
+extern "C" int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* stream) {
+    SLIME_REQUIRE(B && out && B != out, "gemm_pack_b: null or aliasing pointers");
+    SLIME_REQUIRE(N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "gemm_pack_b: N=%d must be a multiple of 64 and K=%d of 64", N, K);
+    SLIME_REQUIRE(((uintptr_t)B % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_pack_b: pointers must be 16-byte aligned");
+    const size_t total = (size_t)N * K / 8;
+    hipLaunchKernelGGL(pack_b_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const u32x4*)B, (u32x4*)out, N, K);
+    SLIME_CHECK_LAUNCH("gemm_pack_b");
+    return SLIME_OK;
 }
 
 extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,

@@ -37,14 +37,17 @@ __device__ __forceinline__ void store_from_float(void* p, int dtype, size_t i, f
 // One wave per output row.  src >= 0: row src of `table`; src <= -2: row (-2 - src) of `feats`; src == -1: zeros.
 // Equal source / destination dtypes are copied bit for bit (16 B per lane per step when the row allows).
 __global__ void __launch_bounds__(256) splice_rows_kernel(const void* table, int table_dtype, const void* feats, int feats_dtype,
-                                                          const long long* src, void* out, int out_dtype, long rows, int H) {
+                                                          const long long* src, void* out, int out_dtype, long rows, int H,
+                                                          long table_rows, long feat_rows) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const long long s = src[r];
     const int es_out = out_dtype == SLIME_F32 ? 4 : 2;
     char* o = reinterpret_cast<char*>(out) + (size_t)r * H * es_out;
-    if (s == -1) {
+    // a source row outside its tensor is never dereferenced: the row is zeroed (the host plan raises on such ids first, as
+    // nn.Embedding does; this is the device-side backstop for direct C-ABI callers)
+    if (s == -1 || (s >= 0 && s >= table_rows) || (s <= -2 && -2 - s >= feat_rows)) {
         for (int b = lane * 16; b < H * es_out; b += 1024) *reinterpret_cast<u32x4*>(o + b) = u32x4{0u, 0u, 0u, 0u};
         return;
     }
@@ -69,7 +72,8 @@ extern "C" int slime_splice_rows(const void* table, int table_dtype, long table_
     SLIME_REQUIRE((H * (out_dtype == SLIME_F32 ? 4 : 2)) % 16 == 0, "splice_rows: rows must be multiples of 16 bytes (H=%d)", H);
     SLIME_REQUIRE(((uintptr_t)out % 16) == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)feats % 16) == 0, "splice_rows: pointers must be 16-byte aligned");
     hipLaunchKernelGGL(splice_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table, table_dtype,
-                       feats, feats_dtype, reinterpret_cast<const long long*>(src), out, out_dtype, rows, H);
+                       feats, feats_dtype, reinterpret_cast<const long long*>(src), out, out_dtype, rows, H,
+                       table ? table_rows : 0, feats ? feat_rows : 0);
     SLIME_CHECK_LAUNCH("splice_rows");
     return SLIME_OK;
 }
@@ -407,13 +411,13 @@ extern "C" size_t slime_llama_attn_workspace_bytes(const slime_llama_attn_desc* 
     return qkv + ctx;
 }
 
-extern "C" int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
-                                        const int32_t* kv_start, const int32_t* kv_len, int batch, int S, void* out, int out_dtype,
-                                        void* ws, size_t ws_bytes, void* stream) {
+// One implementation behind both entry points: resid == NULL -> out = o_proj(ctx) (T or fp32); else the fused residual form.
+static int llama_attn_run(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids, const int32_t* kv_start,
+                          const int32_t* kv_len, int batch, int S, void* out, int out_dtype, float* resid, void* next_hidden,
+                          float* next_stats, void* ws, size_t ws_bytes, void* stream) {
     int rc = llama_validate(d);
     if (rc != SLIME_OK) return rc;
-    SLIME_REQUIRE(hidden && position_ids && out && batch > 0 && S > 0, "llama_attn: bad input");
-    SLIME_REQUIRE(out_dtype == d->dtype || out_dtype == SLIME_F32, "llama_attn: out dtype must be the operand type or F32");
+    SLIME_REQUIRE(hidden && position_ids && batch > 0 && S > 0, "llama_attn: bad input");
     const size_t need = slime_llama_attn_workspace_bytes(d, batch, S);
     if (!ws || ws_bytes < need || ((uintptr_t)ws % 256) != 0) {
         slime_set_error("llama_attn: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, need);
@@ -423,8 +427,11 @@ extern "C" int slime_llama_attn_forward(const slime_llama_attn_desc* d, const vo
     const int NQKV = (HQ + 2 * HKV) * DH, M = batch * S;
     char* qkv = (char*)ws;
     char* ctx = qkv + align_up((size_t)M * NQKV * 2, 256);
+    slime_gemm_args ga{};
     // q/k/v projections as one GEMM (monkey patch :31-45; Llama has no projection biases)
-    rc = slime_gemm(hidden, D, d->w_qkv, nullptr, qkv, NQKV, M, NQKV, D, d->dtype, SLIME_EPI_BIAS_T, stream);
+    ga.A = hidden; ga.lda = D; ga.B = d->w_qkv; ga.B_frag = d->w_qkv_frag; ga.C = qkv; ga.ldc = NQKV; ga.M = M; ga.N = NQKV; ga.K = D;
+    ga.dtype = d->dtype; ga.epilogue = SLIME_EPI_BIAS_T;
+    rc = slime_gemm_ex(&ga, stream);
     if (rc != SLIME_OK) return rc;
     // RoPE on q and k (:51-54); q also takes head_dim^-0.5 * log2(e)
     rc = slime_rope(qkv, NQKV, position_ids, M, HQ + HKV, HQ, DH, d->inv_freq, 0.08838834764831845f * 1.4426950408889634f, d->dtype, stream);
@@ -433,7 +440,30 @@ extern "C" int slime_llama_attn_forward(const slime_llama_attn_desc* d, const vo
                                  qkv + (size_t)(HQ + HKV) * DH * 2, (long)S * NQKV, NQKV, ctx, (long)S * HQ * DH, HQ * DH, batch,
                                  HQ, HKV, DH, S, kv_start, kv_len, d->dtype, stream);
     if (rc != SLIME_OK) return rc;
-    // o_proj (:92)
-    return slime_gemm(ctx, HQ * DH, d->w_o, nullptr, out, D, M, D, HQ * DH, d->dtype,
-                      out_dtype == SLIME_F32 ? SLIME_EPI_BIAS_F32 : SLIME_EPI_BIAS_T, stream);
+    // o_proj (:92), optionally with the decoder layer's residual add in its epilogue
+    ga = slime_gemm_args{};
+    ga.A = ctx; ga.lda = HQ * DH; ga.B = d->w_o; ga.B_frag = d->w_o_frag; ga.M = M; ga.N = D; ga.K = HQ * DH; ga.dtype = d->dtype;
+    if (resid) {
+        ga.C = resid; ga.ldc = D; ga.epilogue = SLIME_EPI_BIAS_RESID_F32_LN; ga.x16 = next_hidden; ga.ldx = D; ga.stats_out = next_stats;
+    } else {
+        ga.C = out; ga.ldc = D; ga.epilogue = out_dtype == SLIME_F32 ? SLIME_EPI_BIAS_F32 : SLIME_EPI_BIAS_T;
+    }
+    return slime_gemm_ex(&ga, stream);
+}
+
+extern "C" int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
+                                        const int32_t* kv_start, const int32_t* kv_len, int batch, int S, void* out, int out_dtype,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    SLIME_REQUIRE(d && out, "llama_attn: bad input");
+    SLIME_REQUIRE(out_dtype == d->dtype || out_dtype == SLIME_F32, "llama_attn: out dtype must be the operand type or F32");
+    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, out, out_dtype, nullptr, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int slime_llama_attn_forward_resid(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
+                                              const int32_t* kv_start, const int32_t* kv_len, int batch, int S, float* resid_f32,
+                                              void* next_hidden, float* next_stats, void* ws, size_t ws_bytes, void* stream) {
+    SLIME_REQUIRE(d && resid_f32 && next_hidden && next_stats, "llama_attn_resid: resid_f32, next_hidden and next_stats are required");
+    SLIME_REQUIRE(d->hidden % 64 == 0, "llama_attn_resid: hidden=%d must be a multiple of 64", d->hidden);
+    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, nullptr, d->dtype, resid_f32, next_hidden, next_stats, ws,
+                          ws_bytes, stream);
 }

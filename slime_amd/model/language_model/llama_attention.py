@@ -69,14 +69,20 @@ def replace_llama_attn_with_hip_attn():
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
                 use_cache=False, **kw):
-        if past_key_value is not None or use_cache:
-            raise NotImplementedError("slime_amd patches the prefill pass only")
+        # prefill only: HF generate() defaults to use_cache=True -- call the patched model with use_cache=False (a present
+        # k/v return for the prefill step would be the natural extension; decode is outside SURVEY section 8)
+        if past_key_value is not None or kw.get("past_key_values") is not None or use_cache:
+            raise NotImplementedError("slime_amd patches the prefill pass only: pass use_cache=False (no KV cache on this path)")
         cfg = self.config
         key = "_slime_packed"
         dt = hidden_states.dtype if hidden_states.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
         cache = self.__dict__.setdefault(key, {})
-        k = (dt, str(self.q_proj.weight.device))
+        # the packed copy is keyed on the identity AND the in-place version of the four weights: load_state_dict, a LoRA merge or
+        # any other in-place edit after the first forward bumps ``_version`` and re-packs instead of silently using stale copies
+        ws = (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.o_proj.weight)
+        k = (dt, str(ws[0].device)) + tuple((w.data_ptr(), w._version) for w in ws)
         if k not in cache:
+            cache.clear()
             cache[k] = ops.pack_llama_attention(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.o_proj.weight,
                                                 cfg.num_attention_heads, cfg.num_key_value_heads, dt, self.q_proj.weight.device,
                                                 float(getattr(cfg, "rope_theta", 500000.0)))

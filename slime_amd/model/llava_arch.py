@@ -313,6 +313,13 @@ class SlimeMetaForCausalLM(ABC):
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels
         merge_type = getattr(self.config, "mm_patch_merge_type", "flat")
+        # The ids come to the host once (the splice plan below is integer host logic).  A token id beyond the embedding table is
+        # rejected HERE, before anything touches the device: the reference's nn.Embedding lookups (llava_arch.py:373, :392 and the
+        # router's text embedding) would hit a device-side assert, which on ROCm aborts the process instead of raising.
+        ids_np = input_ids.detach().cpu().numpy()
+        vocab = self.get_model().embed_tokens.weight.shape[0]
+        if ids_np.size and int(ids_np.max()) >= vocab:
+            raise IndexError(f"input_ids contain token id {int(ids_np.max())} >= vocabulary size {vocab} (index out of range in self)")
         if type(images) is list or images.ndim == 5:
             if type(images) is list:
                 images = [x.unsqueeze(0) if x.ndim == 3 else x for x in images]
@@ -343,7 +350,7 @@ class SlimeMetaForCausalLM(ABC):
         embed = self.get_model().embed_tokens
         table = embed.weight
         dev = table.device
-        src, lab, mask, pos = splice_plan(input_ids.detach().cpu().numpy(),
+        src, lab, mask, pos = splice_plan(ids_np,
                                           None if attention_mask is None else attention_mask.detach().cpu().numpy(),
                                           None if labels is None else labels.detach().cpu().numpy(),
                                           [f.shape[0] for f in feats], getattr(self.config, "tokenizer_model_max_length", None),

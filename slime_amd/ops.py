@@ -61,21 +61,41 @@ class Workspace:
 # primitive wrappers (used by the parity tests and by the modules)
 # ------------------------------------------------------------------------------------------------
 
+def pack_b_frag(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """Copy of the static GEMM operand(s) w T [..., N, K] in MFMA-fragment order (slime_gemm_pack_b; layout in
+    include/slime_hip.h), or None where the direct-B kernel cannot use it (N % 256, K % 64, host tensors)."""
+    if w is None or not w.is_cuda:
+        return None
+    N, K = w.shape[-2], w.shape[-1]
+    if N % 256 != 0 or K % 64 != 0:
+        return None
+    lib = _lib.load()
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    per = N * K * w.element_size()
+    assert lib.slime_gemm_packed_b_bytes(N, K) == per
+    for i in range(w.numel() // (N * K)):
+        _lib.check(lib.slime_gemm_pack_b(w.data_ptr() + i * per, N, K, out.data_ptr() + i * per, _stream()), "slime_gemm_pack_b")
+    return out
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]."""
+         out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]; w_frag = pack_b_frag(w) (optional)."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         odt = a.dtype if epilogue <= _lib.EPI_BIAS_GELU_T else torch.float32
         out = torch.empty((M, N), dtype=odt, device=a.device)
-    _lib.check(lib.slime_gemm(_ptr(a), a.stride(0), _ptr(w), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
-                              dtype_code(a.dtype), epilogue, _stream()), "slime_gemm")
+    g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(out), ldc=out.stride(0), M=M, N=N, K=K,
+                      dtype=dtype_code(a.dtype), epilogue=epilogue, B_frag=_ptr(w_frag))
+    _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return out
 
 
-def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], h: torch.Tensor):
+def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], h: torch.Tensor,
+                     w_frag: Optional[torch.Tensor] = None):
     """h (fp32, in place) += a @ w.T + bias; returns (x16 = T(h), stats [M, N/64, 2]): SLIME_EPI_BIAS_RESID_F32_LN."""
     lib = _lib.load()
     M, K = a.shape
@@ -83,13 +103,14 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     x16 = torch.empty((M, N), dtype=a.dtype, device=a.device)
     stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
     g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(h), ldc=h.stride(0), M=M, N=N, K=K,
-                      dtype=dtype_code(a.dtype), epilogue=_lib.EPI_BIAS_RESID_F32_LN, x16=_ptr(x16), ldx=N, stats_out=_ptr(stats))
+                      dtype=dtype_code(a.dtype), epilogue=_lib.EPI_BIAS_RESID_F32_LN, x16=_ptr(x16), ldx=N, stats_out=_ptr(stats),
+                      B_frag=_ptr(w_frag))
     _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return x16, stats
 
 
 def gemm_ln_consumer(x16: torch.Tensor, stats: torch.Tensor, w_folded: torch.Tensor, bias_folded: torch.Tensor, colsum: torch.Tensor,
-                     eps: float, epilogue: int) -> torch.Tensor:
+                     eps: float, epilogue: int, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """epi(LayerNorm(x16) @ W.T + b) with the LayerNorm folded: w_folded = T(W diag(gamma)), bias_folded = b + W beta,
     colsum = row sums of w_folded; stats from the producer.  Output T [M, N]."""
     lib = _lib.load()
@@ -98,7 +119,7 @@ def gemm_ln_consumer(x16: torch.Tensor, stats: torch.Tensor, w_folded: torch.Ten
     out = torch.empty((M, N), dtype=x16.dtype, device=x16.device)
     g = _lib.GemmArgs(A=_ptr(x16), lda=x16.stride(0), B=_ptr(w_folded), bias=_ptr(bias_folded), C=_ptr(out), ldc=N, M=M, N=N, K=K,
                       dtype=dtype_code(x16.dtype), epilogue=epilogue, ln_stats=_ptr(stats), ln_groups=stats.shape[1],
-                      ln_colsum=_ptr(colsum), ln_eps=float(eps))
+                      ln_colsum=_ptr(colsum), ln_eps=float(eps), B_frag=_ptr(w_frag))
     _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return out
 
@@ -223,11 +244,14 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
         T["w_fc1"], T["b_fc1"], T["colsum_fc1"] = dev_stack(w1), dev_stack(b1), dev_stack(c1)
         T["w_o"], T["b_o"] = stack(p + "self_attn.out_proj.weight", tt), stack(p + "self_attn.out_proj.bias", f32)
         T["w_fc2"], T["b_fc2"] = stack(p + "mlp.fc2.weight", tt), stack(p + "mlp.fc2.bias", f32)
+        # fragment-order copies for the direct-B GEMM kernel (None at geometries it does not serve: the descriptor field stays NULL)
+        for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
+            T[name + "_frag"] = pack_b_frag(T[name])
     d = _lib.VitDesc()
     d.hidden, d.inter, d.heads, d.layers_run = D, Fi, cfg.num_attention_heads, L
     d.image, d.patch, d.kpad, d.dtype, d.eps = cfg.image_size, cfg.patch_size, kpad, dtype_code(dtype), cfg.layer_norm_eps
     for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "w_qkv", "b_qkv", "colsum_qkv", "w_o", "b_o",
-                 "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2"):
+                 "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2", "w_qkv_frag", "w_o_frag", "w_fc1_frag", "w_fc2_frag"):
         setattr(d, name, T[name].data_ptr() if name in T and T[name] is not None else None)
     return PackedTower(cfg, dtype, L, T, d)
 
@@ -266,10 +290,10 @@ def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[tor
     return (out, hidden) if want_hidden else out
 
 
-def gemm_kernel_name(M: int, N: int, K: int, dtype: torch.dtype, epilogue: int) -> str:
+def gemm_kernel_name(M: int, N: int, K: int, dtype: torch.dtype, epilogue: int, has_b_frag: bool = False) -> str:
     lib = _lib.load()
     buf = C.create_string_buffer(128)
-    _lib.check(lib.slime_gemm_kernel_name(M, N, K, dtype_code(dtype), epilogue, buf, 128), "slime_gemm_kernel_name")
+    _lib.check(lib.slime_gemm_kernel_name(M, N, K, dtype_code(dtype), epilogue, int(has_b_frag), buf, 128), "slime_gemm_kernel_name")
     return buf.value.decode()
 
 
@@ -278,11 +302,12 @@ def tower_kernel_names(pt: PackedTower, n_crops: int) -> Dict[int, str]:
     cfg = pt.cfg
     M, D, Fi = n_crops * cfg.seq_len, cfg.hidden_size, cfg.intermediate_size
     t = "F16" if pt.dtype == torch.float16 else "BF16"
-    return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T),
+    fr = {k: pt.tensors.get(k + "_frag") is not None for k in ("w_qkv", "w_o", "w_fc1", "w_fc2")}
+    return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T, fr["w_qkv"]),
             2: f"attn64r_kernel<{t}>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
-            5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T),
-            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN),
-            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN)}
+            5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T, fr["w_fc1"]),
+            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_o"]),
+            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_fc2"])}
 
 
 @dataclass
@@ -336,10 +361,12 @@ def pack_resampler(sd: Dict[str, torch.Tensor], dim: int, heads: int, n_kv: int,
          "w_k": tt(in_w[E:2 * E]), "b_k": f32(in_b[E:2 * E]), "w_v": tt(in_w[2 * E:]), "b_v": f32(in_b[2 * E:]),
          "w_o": tt(sd["attn.out_proj.weight"]), "b_o": f32(sd["attn.out_proj.bias"]),
          "ln_post_w": f32(sd["ln_post.weight"]), "ln_post_b": f32(sd["ln_post.bias"])}
+    for k in ("w_k", "w_v", "w_o"):
+        T[k + "_frag"] = pack_b_frag(T[k])
     d = _lib.ResamplerDesc()
     d.dim, d.heads, d.n_query, d.n_kv, d.dtype, d.eps = dim, heads, nq, n_kv, dtype_code(dtype), eps
     for k, v in T.items():
-        setattr(d, k, v.data_ptr())
+        setattr(d, k, None if v is None else v.data_ptr())
     return PackedResampler(dim, heads, nq, n_kv, dtype, T, d)
 
 
@@ -375,10 +402,11 @@ def pack_mlp(w1, b1, w2, b2, dtype: torch.dtype, device) -> PackedMlp:
          "b1": b1.detach().to(device=device, dtype=torch.float32).contiguous(),
          "w2": w2.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous(),
          "b2": b2.detach().to(device=device, dtype=torch.float32).contiguous()}
+    T["w1_frag"], T["w2_frag"] = pack_b_frag(T["w1"]), pack_b_frag(T["w2"])
     d = _lib.MlpDesc()
     d.in_dim, d.hidden, d.dtype = w1.shape[1], w1.shape[0], dtype_code(dtype)
     for k, v in T.items():
-        setattr(d, k, v.data_ptr())
+        setattr(d, k, None if v is None else v.data_ptr())
     return PackedMlp(w1.shape[1], w1.shape[0], dtype, T, d)
 
 
@@ -706,7 +734,15 @@ class PackedLlamaAttention:
     dtype: torch.dtype
     tensors: Dict[str, torch.Tensor]
     desc: "_lib.LlamaAttnDesc"
-    ws: Workspace = field(default_factory=Workspace)
+
+    @property
+    def ws(self) -> Workspace:
+        """The layers of a language model run one after the other on one stream: they share ONE grow-only scratch buffer per
+        device (a Workspace per packed layer kept 32 x ~200 MB alive at the SliME-8B prefill shapes)."""
+        return _LLAMA_WS
+
+
+_LLAMA_WS = Workspace()
 
 
 def llama_inv_freq(head_dim: int, theta: float) -> torch.Tensor:
@@ -727,18 +763,34 @@ def pack_llama_attention(wq, wk, wv, wo, n_heads: int, n_kv_heads: int, dtype: t
 
     T = {"w_qkv": tt(torch.cat([wq.detach().float().cpu(), wk.detach().float().cpu(), wv.detach().float().cpu()], 0)),
          "w_o": tt(wo), "inv_freq": llama_inv_freq(dh, rope_theta).to(device)}
+    T["w_qkv_frag"], T["w_o_frag"] = pack_b_frag(T["w_qkv"]), pack_b_frag(T["w_o"])
     d = _lib.LlamaAttnDesc()
     d.hidden, d.n_heads, d.n_kv_heads, d.head_dim, d.dtype = D, n_heads, n_kv_heads, dh, dtype_code(dtype)
     for k, v in T.items():
-        setattr(d, k, v.data_ptr())
+        setattr(d, k, None if v is None else v.data_ptr())
     return PackedLlamaAttention(D, n_heads, n_kv_heads, dh, dtype, T, d)
+
+
+_RANGE_CACHE: Dict[int, tuple] = {}
 
 
 def token_ranges(attention_mask: Optional[torch.Tensor]):
     """Key-padding mask [B, S] -> (start, length) int32 [B] of the token run of every sequence.  Prefill masks are
-    contiguous runs (right or left padding, llava_arch.py:435-455); anything else is rejected.  Host-side check: one D2H."""
+    contiguous runs (right or left padding, llava_arch.py:435-455); anything else is rejected.  Host-side check: one D2H --
+    per MASK TENSOR, not per layer: the 32 layers of a forward pass the same tensor, so the result is cached on its identity
+    (data pointer, shape, in-place version counter)."""
     if attention_mask is None:
         return None, None
+    key = (attention_mask.data_ptr(), tuple(attention_mask.shape), attention_mask.dtype, attention_mask._version, str(attention_mask.device))
+    hit = _RANGE_CACHE.get(0)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    start, length = _token_ranges(attention_mask)
+    _RANGE_CACHE[0] = (key, start, length)
+    return start, length
+
+
+def _token_ranges(attention_mask: torch.Tensor):
     m = attention_mask.ne(0)
     length = m.sum(1)
     start = torch.where(length > 0, m.to(torch.int8).argmax(1), torch.zeros_like(length))
@@ -750,6 +802,48 @@ def token_ranges(attention_mask: Optional[torch.Tensor]):
     return start.to(torch.int32).contiguous(), length.to(torch.int32).contiguous()
 
 
+def _position_ids(position_ids: Optional[torch.Tensor], B: int, S: int, device) -> torch.Tensor:
+    """int32 [B, S] on the device.  HF passes position_ids of shape [1, S] (LlamaModel builds them from cache_position when
+    the caller gives None, and prepare_inputs_labels_for_multimodal returns None in that case) and lets cos[position_ids]
+    broadcast over the batch; the kernels index one entry per row, so the broadcast is materialised here."""
+    if position_ids is None:
+        position_ids = torch.arange(S, device=device)[None]
+    if position_ids.dim() == 1:
+        position_ids = position_ids[None]
+    if position_ids.dim() != 2 or position_ids.shape[1] != S or position_ids.shape[0] not in (1, B):
+        raise ValueError(f"position_ids of shape {tuple(position_ids.shape)} do not broadcast to ({B}, {S})")
+    pos = position_ids.to(device=device, dtype=torch.int32).expand(B, S).contiguous()
+    assert pos.shape == (B, S)
+    return pos
+
+
+def llama_attention_forward_resid(pa: PackedLlamaAttention, hidden: torch.Tensor, resid: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+                                  attention_mask: Optional[torch.Tensor] = None, next_hidden: Optional[torch.Tensor] = None,
+                                  next_stats: Optional[torch.Tensor] = None):
+    """The attention sub-layer with the decoder layer's residual add in o_proj's epilogue (slime_llama_attn_forward_resid):
+    ``resid`` fp32 [B, S, D] is updated IN PLACE, ``next_hidden`` T [B, S, D] = T(resid) is what the next layer consumes.
+    Returns (next_hidden, next_stats [B*S, D/64, 2])."""
+    lib = _lib.load()
+    _require_cuda(hidden, "hidden")
+    B, S, D = hidden.shape
+    assert D == pa.hidden and resid.dtype == torch.float32 and resid.is_contiguous() and tuple(resid.shape) == (B, S, D)
+    x = hidden.to(pa.dtype).contiguous()
+    pos = _position_ids(position_ids, B, S, x.device)
+    start, length = token_ranges(None if attention_mask is None else attention_mask.to(x.device))
+    if next_hidden is None:
+        next_hidden = torch.empty((B, S, D), dtype=pa.dtype, device=x.device)
+    if next_stats is None:
+        next_stats = torch.empty((B * S, D // 64, 2), dtype=torch.float32, device=x.device)
+    assert next_hidden.data_ptr() != x.data_ptr(), "the layer's input rows are read by its own q/k/v GEMM only, but keep two buffers"
+    need = lib.slime_llama_attn_workspace_bytes(C.byref(pa.desc), B, S)
+    ws = pa.ws.get(need, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_llama_attn_forward_resid(C.byref(pa.desc), x.data_ptr(), pos.data_ptr(), _ptr(start), _ptr(length), B, S,
+                                                  resid.data_ptr(), next_hidden.data_ptr(), next_stats.data_ptr(), base,
+                                                  ws.numel() - (base - ws.data_ptr()), _stream()), "slime_llama_attn_forward_resid")
+    return next_hidden, next_stats
+
+
 def llama_attention_forward(pa: PackedLlamaAttention, hidden: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
                             attention_mask: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """hidden [B, S, D] -> [B, S, D]: q/k/v projection, RoPE, causal GQA attention over the un-padded tokens, o_proj."""
@@ -758,9 +852,7 @@ def llama_attention_forward(pa: PackedLlamaAttention, hidden: torch.Tensor, posi
     B, S, D = hidden.shape
     assert D == pa.hidden
     x = hidden.to(pa.dtype).contiguous()
-    if position_ids is None:
-        position_ids = torch.arange(S, device=x.device)[None].expand(B, S)
-    pos = position_ids.to(device=x.device, dtype=torch.int32).contiguous()
+    pos = _position_ids(position_ids, B, S, x.device)
     start, length = token_ranges(None if attention_mask is None else attention_mask.to(x.device))
     out_dtype = out_dtype or hidden.dtype
     kernel_out = torch.float32 if out_dtype == torch.float32 else pa.dtype

@@ -40,10 +40,13 @@ def _kernel_notes(so_path, tmp_path):
 def test_hand_scheduled_kernels_do_not_spill(which, tmp_path):
     kernels = _kernel_notes(_lib.LIB_PATH if which == "product" else _lib.DIAG_LIB_PATH, tmp_path)
     assert kernels, "no kernels found in the code object"
-    watched = [n for n in kernels if re.search(r"attn32_kernel|prefill32_kernel|attn64r_kernel|gemm_w4_kernel|prefill_attn_kernel", n)]
+    watched = [n for n in kernels if re.search(r"attn32_kernel|prefill32_kernel|attn64r_kernel|gemm_w4_kernel|gemm_db_kernel|prefill_attn_kernel", n)]
     if which == "diag":
         assert any("attn32_kernel" in n for n in watched), "the diagnostic library lost the attn32 alternative"
     assert any("gemm_w4_kernel" in n for n in watched) and any("prefill32_kernel" in n for n in watched)
+    assert any("gemm_db_kernel" in n for n in watched)
+    # two workgroups per CU is the point of the direct-B kernel: at most 256 registers per lane (VGPR + AGPR)
+    assert all(kernels[n]["vgpr_count"] <= 256 for n in watched if "gemm_db_kernel" in n)
     for n in watched:
         if "attn32_kernel" in n or "prefill32_kernel" in n:
             assert kernels[n]["private_segment_fixed_size"] == 0 and kernels[n]["vgpr_spill_count"] == 0, (n, kernels[n])

@@ -84,6 +84,129 @@ def test_gemm_production_shapes(dev, dtype, M, N, K):
     _check_all_epilogues(dev, dtype, M, N, K)
 
 
+# ---- direct-B kernel (round 3): the static operand in MFMA-fragment order, 128 x 256 tiles, two workgroups per CU ----
+def _frag_order_reference(w):
+    """slime_gemm_pack_b's documented layout (include/slime_hip.h) as a torch permutation:
+    out[t][s][f][lane][e] = w[64 t + 32 (f >> 1) + 8 ((lane & 15) >> 2) + 4 (f & 1) + (lane & 3)][32 s + 8 (lane >> 4) + e]."""
+    N, K = w.shape
+    v = w.view(N // 64, 2, 4, 2, 4, K // 32, 4, 8)          # t, p, g, h, q, s, lq, e   (n = 64t + 32p + 8g + 4h + q)
+    return v.permute(0, 5, 1, 3, 6, 2, 4, 7).contiguous().view(N, K)    # t, s, p, h (f = 2p + h), lq, g, q (lane = 16 lq + 4g + q), e
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(256, 64), (1024, 1024), (3072, 1024), (1024, 4096)])
+def test_gemm_pack_b_layout(dev, dtype, N, K):
+    """The fragment-order copy is a pure permutation of 16-byte chunks: bit-exact against the documented index map."""
+    from slime_amd import ops
+    w = _rand((N, K), dtype, dev, 11)
+    wf = ops.pack_b_frag(w)
+    assert wf is not None and wf.shape == w.shape and wf.dtype == w.dtype
+    assert torch.equal(wf, _frag_order_reference(w))
+    stacked = torch.stack([w, w.flip(0)])                  # per-layer stacks are packed slice by slice
+    wf2 = ops.pack_b_frag(stacked)
+    assert torch.equal(wf2[0], wf) and torch.equal(wf2[1], _frag_order_reference(w.flip(0).contiguous()))
+    assert ops.pack_b_frag(_rand((384, 128), dtype, dev, 12)) is None       # N % 256: the kernel does not serve it
+
+
+def _check_direct_b(dev, dtype, M, N, K, forced):
+    """gemm_db_kernel against (a) fp32 torch on the same rounded operands and (b) the LDS-staged kernels BIT FOR BIT (same
+    k order per accumulator, same epilogue code), every epilogue incl. both sides of the LayerNorm fold."""
+    from slime_amd import ops, _lib
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    assert wf is not None
+    if not forced:
+        # the dispatch rule (gemm.hip auto_tile): fragment-order B -> direct-B kernel, except sub-round grids with K > 2048
+        sub_round_long_k = K > 2048 and ((M + 255) // 256) * (N // 256) < 256
+        assert ("gemm_db_kernel" in ops.gemm_kernel_name(M, N, K, dtype, _lib.EPI_BIAS_T, True)) == (not sub_round_long_k)
+        assert "gemm_db_kernel" not in ops.gemm_kernel_name(M, N, K, dtype, _lib.EPI_BIAS_T, False)
+    ref = a.float() @ w.float().t() + bias
+    for epi, fn, tol in ((_lib.EPI_BIAS_F32, lambda r: r, TOL_F32), (_lib.EPI_BIAS_T, lambda r: r, TOL_T[dtype]),
+                         (_lib.EPI_BIAS_QUICKGELU_T, lambda r: r * torch.sigmoid(1.702 * r), TOL_T[dtype]),
+                         (_lib.EPI_BIAS_GELU_T, F.gelu, TOL_T[dtype])):
+        got = ops.gemm(a, w, bias, epi, w_frag=wf)
+        assert rel_l2(got.float(), fn(ref)) < tol, epi
+        if not forced:
+            assert torch.equal(got, ops.gemm(a, w, bias, epi)), f"epilogue {epi}: differs from the LDS-staged kernel"
+    got = ops.gemm(a, w, None, _lib.EPI_BIAS_F32, w_frag=wf)
+    assert rel_l2(got, ref - bias) < TOL_F32
+    # residual update, plain and as LayerNorm-fold producer
+    h0 = _rand((M, N), torch.float32, dev, 4, 2.0) + 0.3
+    h1, h2, h3 = h0.clone(), h0.clone(), h0.clone()
+    ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h1, w_frag=wf)
+    assert rel_l2(h1, h0 + ref) < TOL_F32
+    x16, stats = ops.gemm_ln_producer(a, w, bias, h2, w_frag=wf)
+    assert torch.equal(h2, h1) and torch.equal(x16, h2.to(dtype))
+    xr = h2.view(M, N // 64, 64)
+    assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
+    if not forced:
+        x16b, statsb = ops.gemm_ln_producer(a, w, bias, h3)
+        assert torch.equal(h3, h2) and torch.equal(x16b, x16) and torch.equal(statsb, stats)
+    # LayerNorm-fold consumer (needs K = the normalised width, 64-column groups)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, K, generator=g) * 1.5 + 0.8
+    x[:, 7] += 40.0
+    x16 = x.to(dev).to(dtype)
+    xr = x16.float().view(M, K // 64, 64)
+    st = torch.stack([xr.sum(-1), (xr * xr).sum(-1)], -1).contiguous()
+    colsum = w.double().sum(1).float()
+    for code in (_lib.EPI_BIAS_T, _lib.EPI_BIAS_QUICKGELU_T):
+        got = ops.gemm_ln_consumer(x16, st, w, bias, colsum, 1e-5, code, w_frag=wf)
+        r = F.layer_norm(x16.double(), (K,), None, None, 1e-5) @ w.double().t() + bias.double()
+        if code == _lib.EPI_BIAS_QUICKGELU_T:
+            r = r * torch.sigmoid(1.702 * r)
+        assert rel_l2(got.float(), r) < TOL_T[dtype]
+        if not forced:
+            assert torch.equal(got, ops.gemm_ln_consumer(x16, st, w, bias, colsum, 1e-5, code))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(11540, 3072, 1024), (11540, 4096, 1024), (11540, 1024, 4096), (11540, 1024, 1024), (13824, 4096, 4096),
+                                   (5193, 3072, 1024), (23080, 1024, 1024)])
+def test_gemm_direct_b_production_shapes(dev, dtype, M, N, K):
+    """The tower's launch shapes through the PRODUCT library's auto dispatch with B_frag set (20-crop half batch, the stacked
+    adapter MLP, a 9-crop rank shard, a 40-crop batch): gemm_db_kernel, ragged last row tile (11540 = 90 x 128 + 20)."""
+    _check_direct_b(dev, dtype, M, N, K, forced=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128), (128, 256, 192), (129, 256, 128),
+                                   (11540, 1024, 4096), (2885, 1024, 4096)])
+def test_gemm_direct_b_small_and_edge_shapes(dev, dtype, M, N, K):
+    """The same kernel forced (diagnostic build) onto shapes the dispatch would not give it: one k-tile (K = 64: prologue +
+    last-tile body only), two and three k-tiles (every tile-body variant), M < 128, M = 128 exactly, one row over, and the
+    sub-round K = 4096 grids (fc2 at a 20-crop and a 5-crop batch) that the auto rule leaves to the LDS-staged kernels."""
+    from slime_amd import _lib
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(12)
+        try:
+            _check_direct_b(dev, dtype, M, N, K, forced=True)
+        finally:
+            lib.slime_gemm_force_tile(0)
+
+
+def test_gemm_direct_b_determinism_under_load(dev):
+    """Counted waits: a load that is waited for too early shows up as run-to-run differences, not as a large error.  The same
+    GEMM 20 times while a second stream keeps the memory system busy: every result identical."""
+    from slime_amd import ops, _lib
+    dt = torch.bfloat16
+    a = _rand((11540, 1024), dt, dev, 1)
+    w = _rand((4096, 1024), dt, dev, 2, 1024 ** -0.5)
+    bias = _rand((4096,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    first = ops.gemm(a, w, bias, _lib.EPI_BIAS_QUICKGELU_T, w_frag=wf)
+    noise = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    for i in range(20):
+        with torch.cuda.stream(side):
+            noise.add_(1)
+        got = ops.gemm(a, w, bias, _lib.EPI_BIAS_QUICKGELU_T, w_frag=wf)
+        assert torch.equal(got, first), i
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 256, 128), (11540, 1024, 4096), (11540, 1024, 1024)])
 def test_gemm_layernorm_fold_producer(dev, dtype, M, N, K):

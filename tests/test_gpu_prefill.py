@@ -78,6 +78,12 @@ def test_prepare_inputs_labels_for_multimodal_end_to_end(dev):
     # text-only step (decode: one token) and image-free call return the inputs untouched
     one = enc.prepare_inputs_labels_for_multimodal(ids_d[:, :1], None, am_d[:, :1], None, None, px)
     assert one[0] is not None and one[4] is None
+    # a token id beyond the embedding table raises like nn.Embedding does in the reference (llava_arch.py:373), instead of an
+    # out-of-bounds device read
+    bad = ids.clone()
+    bad[0, 5] = 10 ** 6
+    with pytest.raises(IndexError, match="vocabulary"):
+        enc.prepare_inputs_labels_for_multimodal(bad.to(dev), None, am_d, None, lab_d, px, image_sizes=sizes)
 
 
 # ------------------------------------------------------------------------------------------------ RoPE / attention
@@ -302,3 +308,105 @@ def test_prefill_attention_short_sequences(dev, S):
             assert float((got - ref).norm() / ref.norm()) < 6e-3
             if ranges:
                 assert float(o[b, :lo].abs().max() if lo else 0) == 0.0 and float(o[b, hi:].abs().max() if hi < S else 0) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ round 3
+@pytest.fixture(scope="module")
+def llama8b_case():
+    """One attention sub-layer at Llama-3-8B dims (D = 4096, 32 q / 8 kv heads, dh 128), B = 2, S = 1216 (BASELINE config 4's
+    sequence length), right padding on the second sequence; the fp32 oracle result (a few seconds of CPU)."""
+    from oracle import prefill_oracle as P
+    D, HQ, HKV, B, S = 4096, 32, 8, 2, 1216
+    g = torch.Generator().manual_seed(41)
+    w = [torch.randn(n, k, generator=g) * k ** -0.5 for n, k in ((HQ * 128, D), (HKV * 128, D), (HKV * 128, D), (D, HQ * 128))]
+    hidden = torch.randn(B, S, D, generator=g)
+    mask = torch.ones(B, S, dtype=torch.int64)
+    mask[1, 900:] = 0
+    pos = torch.arange(S)[None].expand(B, S).contiguous()
+    ref = P.llama_attention_forward(hidden, w[0], w[1], w[2], w[3], HQ, HKV, pos, mask)
+    return (D, HQ, HKV, B, S), w, hidden, mask, pos, ref
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_llama_attention_real_size_vs_oracle(dev, llama8b_case, dtype):
+    """slime_llama_attn_forward at the shape bench.py --config 4 / 5 times -- the fused q/k/v GEMM
+    (N = 6144, K = 4096) -> RoPE -> prefill32 / eight-wave attention -> o_proj chain, right padding -- against
+    oracle/prefill_oracle.llama_attention_forward (llama_flash_attn_monkey_patch.py:16-93) on the full tensor."""
+    from slime_amd import ops
+    (D, HQ, HKV, B, S), w, hidden, mask, pos, ref = llama8b_case
+    pa = ops.pack_llama_attention(w[0], w[1], w[2], w[3], HQ, HKV, dtype, dev)
+    assert pa.tensors["w_qkv_frag"] is not None and pa.tensors["w_o_frag"] is not None
+    out = ops.llama_attention_forward(pa, hidden.to(dev), pos.to(dev), mask.to(dev), torch.float32).cpu()
+    assert rel_l2(out, ref) < TOL[dtype]
+    worst = ((out - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6))[mask.bool()].max()
+    assert float(worst) < 6 * TOL[dtype]
+    assert float(out[mask == 0].abs().max()) == 0.0
+    # the fused-residual form (decoder layer's residual add in o_proj's epilogue): fp32 stream bit-equal to resid + out,
+    # next_hidden = T(resid), partial sums of the updated rows
+    resid0 = torch.randn(B, S, D, generator=torch.Generator().manual_seed(3)).to(dev)
+    resid = resid0.clone()
+    nxt, stats = ops.llama_attention_forward_resid(pa, hidden.to(dev), resid, pos.to(dev), mask.to(dev))
+    assert torch.equal(resid, resid0 + out.to(dev))
+    assert torch.equal(nxt, resid.to(dtype))
+    r = resid.view(B * S, D // 64, 64)
+    assert rel_l2(stats[..., 0], r.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (r * r).sum(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("form", ["row", "vector", "none"])
+def test_llama_attention_position_ids_broadcast(dev, form):
+    """HF hands the attention position_ids of shape [1, S] (or None) for a batch of B sequences and lets
+    cos[position_ids] broadcast; the kernels index one entry per row.  B = 3 with a [1, S] row, a 1-D vector and None must
+    equal the explicit [B, S] call bit for bit -- through HipLlamaAttention and through the monkey-patched HF forward."""
+    from slime_amd.model.language_model import HipLlamaAttention
+    D, HQ, HKV, B, S = 1024, 8, 2, 3, 70
+    g = torch.Generator().manual_seed(5)
+    m = HipLlamaAttention(D, HQ, HKV, 128, 500000.0, compute_dtype=torch.bfloat16)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * p_.shape[1] ** -0.5)
+    m.to(dev)
+    hidden = torch.randn(B, S, D, generator=g).to(dev)
+    full = torch.arange(S, device=dev)[None].expand(B, S).contiguous()
+    want, _, _ = m(hidden, position_ids=full)
+    pid = {"row": torch.arange(S, device=dev)[None], "vector": torch.arange(S, device=dev), "none": None}[form]
+    got, _, _ = m(hidden, position_ids=pid)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError, match="broadcast"):
+        m(hidden, position_ids=torch.arange(S, device=dev)[None].expand(2, S))
+    # the patched HF module (llama_flash_attn_monkey_patch.py:105-115 counterpart)
+    from transformers.models.llama import modeling_llama as M
+    from transformers import LlamaConfig
+    from slime_amd.model.language_model.llama_attention import replace_llama_attn_with_hip_attn
+    orig = M.LlamaAttention.forward
+    try:
+        replace_llama_attn_with_hip_attn()
+        cfg = LlamaConfig(hidden_size=D, num_attention_heads=HQ, num_key_value_heads=HKV, head_dim=128, intermediate_size=256,
+                          num_hidden_layers=1, rope_theta=500000.0, vocab_size=64)
+        att = M.LlamaAttention(cfg, layer_idx=0)
+        att.load_state_dict({k: v for k, v in m.state_dict().items()}, strict=False)
+        att.to(dev)
+        got2, _, _ = att(hidden, attention_mask=None, position_ids=pid)
+        assert torch.equal(got2, want)
+        # stale-cache guard: an in-place weight edit after the first forward must be seen
+        with torch.no_grad():
+            att.o_proj.weight.mul_(2.0)
+        got3, _, _ = att(hidden, attention_mask=None, position_ids=pid)
+        assert rel_l2(got3.float().cpu(), (2.0 * want).float().cpu()) < 2e-2 and not torch.equal(got3, got2)
+        with pytest.raises(NotImplementedError, match="use_cache=False"):
+            att(hidden, attention_mask=None, position_ids=pid, use_cache=True)
+    finally:
+        M.LlamaAttention.forward = orig
+
+
+def test_splice_out_of_range_sources(dev):
+    """a token id >= vocabulary size raises on the host (nn.Embedding's behaviour, llava_arch.py:373); the kernel never
+    dereferences a source row outside its tensor (direct C-ABI callers get a zero row)."""
+    from slime_amd import ops
+    table = torch.arange(5 * 64, dtype=torch.float32).view(5, 64).to(dev)
+    feats = -torch.arange(3 * 64, dtype=torch.float32).view(3, 64).to(dev)
+    src = torch.tensor([0, 4, 5, 1000000, -2, -4, -5, -1000, -1], dtype=torch.int64, device=dev)
+    out = ops.splice_rows(table, feats, src, torch.float32).cpu()
+    assert torch.equal(out[0], table[0].cpu()) and torch.equal(out[1], table[4].cpu())
+    assert torch.equal(out[4], feats[0].cpu()) and torch.equal(out[5], feats[2].cpu())
+    for r in (2, 3, 6, 7, 8):
+        assert float(out[r].abs().max()) == 0.0
