@@ -65,9 +65,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run gather + adapter of a step on the tower's stream instead of a second stream")
-    ap.add_argument("--gather", choices=["chunked", "oneshot", "compressed"], default="chunked",
-                    help="config 3 exchange: chunked async all-gather under the tower (default), one blocking all-gather, or "
-                         "post_qformer on the shard + gather of compressed local crops")
+    ap.add_argument("--gather", choices=["auto", "chunked", "oneshot", "compressed"], default="auto",
+                    help="strong-scaling exchange: auto = slime_amd.dist.choose_chunk (measured tower latency curve + transfer model: "
+                         "one pass + one all-gather at every per-rank size of configs 2 / 3 / 5), chunked = micro-batches of 3 with "
+                         "asynchronous gathers (round 2's default), oneshot, or compressed (post_qformer on the shard first)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="config 2 only: strong = the SAME 40 crops block-partitioned over the ranks (what BASELINE's '1/2/4/8 MI355X' "
+                         "reads as for a fixed batch); default weak = 40 crops per GPU")
     return ap.parse_args()
 
 
@@ -193,7 +197,11 @@ def pmc_traffic(rocprof_name):
 
 def main():
     args = parse()
-    C = CONFIGS[args.config]
+    C = dict(CONFIGS[args.config])
+    if args.scaling is not None:
+        if args.config != 2:
+            raise SystemExit("--scaling applies to --config 2 (configs 3 / 5 are strong, config 4 is single-GPU)")
+        C["scaling"] = args.scaling
     IMAGES, LOCAL, (NW, NH) = C["images"], C["local"], C["grid"]
     CPI = 1 + LOCAL
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -282,6 +290,9 @@ def main():
         my_images = list(range(IMAGES)) if args.config == 5 else D.image_shard(IMAGES, world, rank)
         lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
 
+        per_rank_crops = -(-n_step // world)
+        chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world)}.get(args.gather, 0)
+
         def tower_fn(x):
             return vm.encode(x, -2, False, dt)
 
@@ -291,7 +302,7 @@ def main():
         def produce():
             if args.gather == "compressed":
                 return D.sharded_tower_compressed(tower_fn, compress_fn, pixels, CPI, (576, 1024), g * g, dt)
-            return D.sharded_tower(tower_fn, pixels, (576, 1024), dt, chunk=3 if args.gather == "chunked" else 0)
+            return D.sharded_tower(tower_fn, pixels, (576, 1024), dt, chunk=chunk)
 
         def tail(feats):
             if hi_i == lo_i:
@@ -302,7 +313,7 @@ def main():
                                                          NW, NH, True, -1, dt)
             return ops.adapter_forward(pg, post, feats[lo_i * CPI:hi_i * CPI], hi_i - lo_i, LOCAL, NW, NH, True, -1, dt)
         full_b, comp_b = D.gather_bytes(n_step, CPI, world)
-        extra_cfg.update({"gather": args.gather, "gather_bytes_per_rank": comp_b if args.gather == "compressed" else full_b,
+        extra_cfg.update({"gather": args.gather, "gather_chunk": chunk, "gather_bytes_per_rank": comp_b if args.gather == "compressed" else full_b,
                           "crops_per_rank_padded": -(-n_step // world), "images_owned_by_rank0": len(my_images)})
 
     # config 4: splice + 32 Llama-3-8B attention sub-layers over the spliced sequences

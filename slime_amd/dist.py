@@ -33,6 +33,53 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
     return list(range(lo, hi))
 
 
+# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/rank_shapes.py, profiles/r03_small_batch_latency.json):
+# a pass costs ~3.1 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us kernels) and ~0.33 ms per crop
+# beyond ~16 crops, where the GEMM grids fill the chip.
+TOWER_MS = {1: 3.14, 2: 3.16, 3: 3.25, 4: 3.48, 5: 3.71, 6: 3.86, 8: 4.59, 9: 4.96, 10: 5.32, 12: 5.73, 14: 6.95, 16: 7.24, 17: 7.55,
+            20: 8.52, 24: 10.11, 34: 13.42, 40: 15.22}
+
+
+def tower_ms(n: int) -> float:
+    """Measured tower latency for n crops (piece-wise linear through TOWER_MS; 0.334 ms per crop past the table)."""
+    if n <= 0:
+        return 0.0
+    ks = sorted(TOWER_MS)
+    if n >= ks[-1]:
+        return TOWER_MS[ks[-1]] + 0.334 * (n - ks[-1])
+    for a, b in zip(ks, ks[1:]):
+        if a <= n <= b:
+            return TOWER_MS[a] + (TOWER_MS[b] - TOWER_MS[a]) * (n - a) / (b - a)
+    return TOWER_MS[ks[0]]
+
+
+def gather_ms(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0) -> float:
+    """All-gather time model for per_rank crops of bf16 features per rank: every rank receives (world - 1) blocks.  xGMI is
+    point to point (7 links x ~153 GB/s per GPU): a ring is bound by ONE link, a direct exchange uses all of them; 100 GB/s of
+    effective per-rank receive bandwidth is the conservative (ring) end, plus ~30 us of collective launch latency."""
+    if world <= 1 or per_rank <= 0:
+        return 0.0
+    return 0.03 + (world - 1) * per_rank * bytes_per_crop / (link_gb_s * 1e6)
+
+
+def choose_chunk(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0) -> int:
+    """Micro-batch size for ``sharded_tower`` (0 = one tower pass + one all-gather).  Chunking hides all but the last
+    micro-batch's transfer under the remaining tower work but pays the tower's per-pass floor once per extra micro-batch:
+    it is chosen only where the modelled saving exceeds that cost.  With the measured curve that is never the case at the
+    per-rank sizes of BASELINE configs 2 / 3 / 5 (5 ... 34 crops: a second pass costs 1.8-3 ms, the whole transfer <= 0.8 ms
+    -- round 2's fixed chunk of 3 turned 9 crops from 4.96 into 9.74 ms); it starts to pay at ~100 crops per rank on 8 GPUs."""
+    if world <= 1 or per_rank < 2:
+        return 0
+    best, best_t = 0, tower_ms(per_rank) + gather_ms(per_rank, world, bytes_per_crop, link_gb_s)
+    for k in (2, 3, 4):                                     # number of micro-batches
+        c = -(-per_rank // k)
+        sizes = [min(c, per_rank - i) for i in range(0, per_rank, c)]
+        t = sum(tower_ms(x) for x in sizes) + gather_ms(sizes[-1], world, bytes_per_crop, link_gb_s)
+        if t < best_t - 0.05:
+            best, best_t = c, t
+    return best
+
+
 def sharded_tower(tower_fn: Callable[[torch.Tensor], torch.Tensor], crops: torch.Tensor, feat_shape: Tuple[int, int],
                   feat_dtype: torch.dtype = torch.float32, group=None, chunk: int = 0) -> torch.Tensor:
     """Run ``tower_fn`` on this rank's block of ``crops`` ([N,3,S,S], identical on every rank) and all-gather the

@@ -771,22 +771,21 @@ def pack_llama_attention(wq, wk, wv, wo, n_heads: int, n_kv_heads: int, dtype: t
     return PackedLlamaAttention(D, n_heads, n_kv_heads, dh, dtype, T, d)
 
 
-_RANGE_CACHE: Dict[int, tuple] = {}
+_RANGE_CACHE: Dict[str, object] = {}
 
 
 def token_ranges(attention_mask: Optional[torch.Tensor]):
     """Key-padding mask [B, S] -> (start, length) int32 [B] of the token run of every sequence.  Prefill masks are
     contiguous runs (right or left padding, llava_arch.py:435-455); anything else is rejected.  Host-side check: one D2H --
-    per MASK TENSOR, not per layer: the 32 layers of a forward pass the same tensor, so the result is cached on its identity
-    (data pointer, shape, in-place version counter)."""
+    per MASK TENSOR, not per layer: the 32 layers of a forward pass the same tensor object, so the last result is kept together
+    with a reference to that object and reused while the caller hands in the very same object, unmodified (``is`` + the in-place
+    version counter; a data pointer would not do -- the caching allocator recycles addresses)."""
     if attention_mask is None:
         return None, None
-    key = (attention_mask.data_ptr(), tuple(attention_mask.shape), attention_mask.dtype, attention_mask._version, str(attention_mask.device))
-    hit = _RANGE_CACHE.get(0)
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+    if _RANGE_CACHE.get("mask") is attention_mask and _RANGE_CACHE.get("version") == attention_mask._version:
+        return _RANGE_CACHE["start"], _RANGE_CACHE["length"]
     start, length = _token_ranges(attention_mask)
-    _RANGE_CACHE[0] = (key, start, length)
+    _RANGE_CACHE.update(mask=attention_mask, version=attention_mask._version, start=start, length=length)
     return start, length
 
 

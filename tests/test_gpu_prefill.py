@@ -410,3 +410,20 @@ def test_splice_out_of_range_sources(dev):
     assert torch.equal(out[4], feats[0].cpu()) and torch.equal(out[5], feats[2].cpu())
     for r in (2, 3, 6, 7, 8):
         assert float(out[r].abs().max()) == 0.0
+
+
+def test_token_ranges_cache_is_per_tensor_object(dev):
+    """The (start, length) cache of ops.token_ranges must follow the mask OBJECT, not its address: the caching allocator hands
+    a freed mask's address to the next one (this bit the left-padding golden test when the cache was keyed on data_ptr)."""
+    from slime_amd import ops
+    m1 = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 0]], device=dev)
+    s1, l1 = ops.token_ranges(m1)
+    assert s1.tolist() == [0, 0] and l1.tolist() == [3, 2]
+    assert ops.token_ranges(m1)[0] is s1                               # same object, unmodified: cached
+    del m1
+    m2 = torch.tensor([[0, 1, 1, 1], [0, 0, 1, 1]], device=dev)          # very likely the same address
+    s2, l2 = ops.token_ranges(m2)
+    assert s2.tolist() == [1, 2] and l2.tolist() == [3, 2]
+    m2[0, 0] = 1                                                         # in-place edit: version bump
+    s3, l3 = ops.token_ranges(m2)
+    assert s3.tolist() == [0, 2] and l3.tolist() == [4, 2]
