@@ -69,6 +69,10 @@ def parse():
                     help="strong-scaling exchange: auto = slime_amd.dist.choose_chunk (measured tower latency curve + transfer model: "
                          "one pass + one all-gather at every per-rank size of configs 2 / 3 / 5), chunked = micro-batches of 3 with "
                          "asynchronous gathers (round 2's default), oneshot, or compressed (post_qformer on the shard first)")
+    ap.add_argument("--prefill-shard", choices=["replicated", "heads"], default="replicated",
+                    help="config 5 with N > 1: replicated = every rank runs all 32 attention sub-layers (north_star's split: only the ViT "
+                         "crops are sharded); heads = kv-head sharding (slime_amd.dist.head_sharded_attention: column-sliced q/k/v, local "
+                         "attention, row-parallel o_proj + one all-reduce per layer) -- opt-in until measured on a multi-GPU box")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="config 2 only: strong = the SAME 40 crops block-partitioned over the ranks (what BASELINE's '1/2/4/8 MI355X' "
                          "reads as for a fixed batch); default weak = 40 crops per GPU")
@@ -321,7 +325,9 @@ def main():
     if args.config == 4:
         prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g)
     elif args.config == 5:
-        prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g, sequences=1)
+        prefill = build_prefill(enc, dev, dt, IMAGES, 576 + LOCAL * g * g, sequences=1,
+                                shard=(world, rank) if (args.prefill_shard == "heads" and collective and world > 1) else None)
+        extra_cfg["prefill_shard"] = args.prefill_shard if world > 1 else "n/a (one GPU)"
 
     def step():
         feats = produce()
@@ -424,7 +430,7 @@ def main():
         dist.destroy_process_group()
 
 
-def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32, sequences=None):
+def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32, sequences=None, shard=None):
     """Second half of configs 4 / 5: embed table + 32 Llama-3-8B attention sub-layers (random init) and the splice plan.
     Config 4: one sequence per image, [text/2, <image>, text/2].  Config 5 (sequences=1): ONE sequence holding all frames,
     [text chunk, <image>] x n_images + tail.  Returns a callable (visual tokens [n_images, rows, 4096] bf16) -> hidden states."""
@@ -453,22 +459,30 @@ def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32
     o_scale = 1.0 if os.environ.get("SLIME_BENCH_EXPLODING_LOGITS") == "1" else (2.0 * layers) ** -0.5
     for _ in range(layers):
         w = [torch.randn(n, k, generator=g, dtype=torch.float32) * (k ** -0.5) for n, k in ((HQ * 128, D), (HKV * 128, D), (HKV * 128, D), (D, HQ * 128))]
-        packs.append(ops.pack_llama_attention(w[0], w[1], w[2], w[3] * o_scale, HQ, HKV, dt, dev, 500000.0))
+        wq, wk, wv, wo, hq_r, hkv_r = w[0], w[1], w[2], w[3] * o_scale, HQ, HKV
+        if shard is not None:                                   # this rank's kv heads only (slime_amd.dist, --prefill-shard heads)
+            from slime_amd import dist as D_
+            wq, wk, wv, wo, hq_r, hkv_r = D_.shard_llama_attention_weights(wq, wk, wv, wo, HQ, HKV, shard[0], shard[1])
+        packs.append(ops.pack_llama_attention(wq, wk, wv, wo, hq_r, hkv_r, dt, dev, 500000.0))
     M = images * S
     gf_layer = (2.0 * M * (HQ + 2 * HKV) * 128 * D + 2.0 * M * D * HQ * 128 + 4.0 * images * HQ * (S * (S + 1) / 2) * 128) / 1e9
 
     bufs = [torch.empty((images, S, D), dtype=dt, device=dev) for _ in range(2)]
-    stats = torch.empty((M, D // 64, 2), dtype=torch.float32, device=dev)
 
     def run(tokens):
-        # no torch arithmetic in here: the splice writes the fp32 residual stream and the first layer's 16-bit rows (two launches of
-        # the same data-movement kernel); every layer's residual add rides in its o_proj epilogue (slime_llama_attn_forward_resid),
-        # which also emits the next layer's 16-bit rows
+        # no torch arithmetic in here: the splice writes the 16-bit hidden rows, every layer's residual add rides in its o_proj
+        # epilogue (slime_llama_attn_forward_resid: x_next = T(x + self_attn(x)), HF's 16-bit residual stream), ping-pong buffers
         feats = tokens.reshape(-1, tokens.shape[-1])
-        h32 = ops.splice_rows(table, feats, src_d, torch.float32).view(images, S, D)
         x = ops.splice_rows(table, feats, src_d, dt).view(images, S, D)
         for i, p in enumerate(packs):
-            x, _ = ops.llama_attention_forward_resid(p, x, h32, pos_d, None, next_hidden=bufs[i & 1], next_stats=stats)
+            if shard is None:
+                x = ops.llama_attention_forward_resid(p, x, x, pos_d, None, out=bufs[i & 1])
+            else:
+                # head-sharded: rank 0's partial carries the residual (its o_proj epilogue adds it), one all-reduce per layer
+                from slime_amd import dist as D_
+                x = D_.head_sharded_attention(
+                    lambda h, r, p=p, i=i: ops.llama_attention_forward_resid(p, h, r, pos_d, None, out=bufs[i & 1]) if r is not None
+                    else ops.llama_attention_forward(p, h, pos_d, None, dt), x, x)
         return x
 
     def kernel_times():
@@ -505,7 +519,7 @@ def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32
     run.kernel_times = kernel_times
     run.describe = lambda: {"prefill_sequences": images, "prefill_seq_len": S, "llama_layers": layers,
                             "prefill_gflop_per_step": round(gf_layer * layers, 1),
-                            "prefill_note": "attention sub-layers only (q/k/v projection, RoPE, causal GQA, o_proj with the residual add fused into its epilogue: fp32 residual stream); RMSNorm / MLP / lm_head are outside SURVEY section 8"}
+                            "prefill_note": "attention sub-layers only (q/k/v projection, RoPE, causal GQA, o_proj with the residual add fused into its epilogue: out = T(x + attn(x)), 16-bit stream as in HF); RMSNorm / MLP / lm_head are outside SURVEY section 8"}
     return run
 
 

@@ -47,7 +47,8 @@ enum {
     SLIME_EPI_BIAS_GELU_T,       /* exact erf GELU -> T                     (projector/builder.py:53-57) */
     SLIME_EPI_BIAS_F32,          /* -> fp32                                                              */
     SLIME_EPI_BIAS_RESID_F32,    /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
-    SLIME_EPI_BIAS_RESID_F32_LN  /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
+    SLIME_EPI_BIAS_RESID_F32_LN, /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
+    SLIME_EPI_BIAS_RESID_T       /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
 };
 
 int slime_abi_version(void);
@@ -77,6 +78,7 @@ typedef struct {
     const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;     /* consumer side, or NULL / 0 */
     void* x16; int ldx; float* stats_out;                                             /* producer side, or NULL / 0 */
     const void* B_frag;          /* optional: B in MFMA-fragment order (slime_gemm_pack_b), or NULL                  */
+    const void* resid; int ldr;  /* epilogue BIAS_RESID_T: residual rows T [M, ldr] (may alias C), else NULL / 0     */
 } slime_gemm_args;
 int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 
@@ -380,14 +382,13 @@ int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden,
                              void* ws, size_t ws_bytes, void* stream);
 
 /* The same sub-layer with the decoder layer's residual add fused into o_proj's epilogue (HF LlamaDecoderLayer.forward:
- * hidden_states = residual + self_attn(...); the reference reaches it through the patched LlamaAttention.forward,
- * llama_flash_attn_monkey_patch.py:16-93):  resid_f32[M, hidden] += o_proj(attention(hidden))  in place (fp32 residual
- * stream, as in the vision tower), next_hidden T [M, hidden] = T(resid_f32) -- the rows the NEXT layer consumes -- and
- * next_stats fp32 [M, hidden/64, 2] = (sum, sum of squares) of every updated row per 64-column group (what a folded
- * RMSNorm / LayerNorm of the next layer needs; may not be NULL).  No torch arithmetic is left between two layers. */
+ * hidden_states = residual + self_attn(norm(hidden_states)); the reference reaches it through the patched
+ * LlamaAttention.forward, llama_flash_attn_monkey_patch.py:16-93):  out = T(resid + o_proj(attention(hidden))), all T
+ * [batch*S, hidden]; out may alias resid (in-place stream), hidden may be resid itself (no norm in between) but must not alias out.
+ * No torch arithmetic is left between two layers. */
 int slime_llama_attn_forward_resid(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
-                                   const int32_t* kv_start, const int32_t* kv_len, int batch, int S, float* resid_f32,
-                                   void* next_hidden, float* next_stats, void* ws, size_t ws_bytes, void* stream);
+                                   const int32_t* kv_start, const int32_t* kv_len, int batch, int S, const void* resid,
+                                   void* out, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

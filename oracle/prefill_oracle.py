@@ -127,11 +127,13 @@ def apply_rope(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
 
 def llama_attention_forward(hidden: Tensor, wq: Tensor, wk: Tensor, wv: Tensor, wo: Tensor, n_heads: int, n_kv_heads: int,
                             position_ids: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
-                            theta: float = 500000.0) -> Tensor:
+                            theta: float = 500000.0, head_dim: Optional[int] = None) -> Tensor:
     """hidden [B, S, D] fp32 -> [B, S, D].  ``attention_mask`` [B, S] is a key-padding mask (1 = token): attention runs causally
-    over the un-padded tokens of each sequence in their own order; padded positions give zero rows before o_proj."""
+    over the un-padded tokens of each sequence in their own order; padded positions give zero rows before o_proj.
+    ``head_dim`` defaults to D / n_heads (LlamaConfig's default); a head-sharded slice of a layer (tests/test_dist_gloo.py) has
+    fewer heads than D / head_dim and passes it explicitly."""
     B, S, D = hidden.shape
-    dh = D // n_heads
+    dh = head_dim or D // n_heads
     g = n_heads // n_kv_heads
     if position_ids is None:
         position_ids = torch.arange(S)[None].expand(B, S)

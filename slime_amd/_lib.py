@@ -24,7 +24,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 3
 BF16, F16, F32, U8 = 0, 1, 2, 3
-EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN = range(6)
+EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T = range(7)
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -44,7 +44,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_int),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
-                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p)]
+                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int)]
 
 
 class ResamplerDesc(C.Structure):
@@ -133,7 +133,7 @@ _SIGNATURES = {
     "slime_llama_attn_forward": (c_int, [_P(LlamaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_size_t, c_void_p]),
     "slime_llama_attn_forward_resid": (c_int, [_P(LlamaAttnDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                               c_void_p, c_void_p, c_size_t, c_void_p]),
+                                               c_void_p, c_size_t, c_void_p]),
 }
 
 # diagnostic build only (libslime_hip_diag.so): process-global hooks, never exported by the product library

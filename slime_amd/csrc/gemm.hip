@@ -46,6 +46,8 @@ struct GemmArgs {
     // gemm_db_kernel timing ablations (diagnostic build; wrong results): 1 = every tile's epilogue writes rows 0..127 (the stores
     // stay in L2: no HBM write burst), 2 = no epilogue at all
     int db_abl;
+    // epilogue BIAS_RESID_T: 16-bit residual rows added before the rounding (may alias C)
+    const char* resid; int ldr;
 };
 
 // Sum over the four 16-lane rows of a wave (lanes l, l+16, l+32, l+48), result in every row: pure VALU (permlane swaps).
@@ -104,7 +106,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * one_plus_erf;
 }
 
-template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T); };
+template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T || EPI == SLIME_EPI_BIAS_RESID_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
 // columns starting at col_base + 32 p of row row_base + 16 i.
@@ -245,6 +247,44 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                         if ((col_base & 31) == 0 && in_range(row))
                             *reinterpret_cast<float2*>(g.stats_out + ((size_t)row * (g.N >> 6) + ((col_base + 64 * pp) >> 6)) * 2) = make_float2(sx, sq);
                     }
+                }
+            }
+        }
+    } else if constexpr (EPI == SLIME_EPI_BIAS_RESID_T) {
+        // C = T(acc + bias + float(R)): the decoder layer's residual add (16-bit stream, as HF keeps it).  R may alias C, and vmcnt
+        // counts stores too: the residual rows are fetched in register double-buffered batches, one batch ahead of the stores.
+        constexpr int BATCH = (MI >= 2) ? 2 : 1;
+        constexpr int NB = MI / BATCH;
+        u32x4 rb[2][BATCH][NP];
+        auto load_batch = [&](int b, int buf) {
+#pragma unroll
+            for (int ii = 0; ii < BATCH; ++ii) {
+                int row = row_base + (b * BATCH + ii) * 16;
+                if constexpr (!FULL) row = min(row, g.M - 1);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    rb[buf][ii][p] = *reinterpret_cast<const u32x4*>(g.resid + ((size_t)row * g.ldr + col_base + 32 * p) * 2);
+            }
+        };
+        load_batch(0, 0);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b + 1 < NB) load_batch(b + 1, (b + 1) & 1);
+#pragma unroll
+            for (int ii = 0; ii < BATCH; ++ii) {
+                const int i = b * BATCH + ii;
+                const int row = row_base + i * 16;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const u32x4 r = rb[b & 1][ii][p];
+                    float v[8];
+                    v[0] = acc[i][2 * p][0] + bias[p][0] + T::lo(r[0]); v[1] = acc[i][2 * p][1] + bias[p][1] + T::hi(r[0]);
+                    v[2] = acc[i][2 * p][2] + bias[p][2] + T::lo(r[1]); v[3] = acc[i][2 * p][3] + bias[p][3] + T::hi(r[1]);
+                    v[4] = acc[i][2 * p + 1][0] + bias[p][4] + T::lo(r[2]); v[5] = acc[i][2 * p + 1][1] + bias[p][5] + T::hi(r[2]);
+                    v[6] = acc[i][2 * p + 1][2] + bias[p][6] + T::lo(r[3]); v[7] = acc[i][2 * p + 1][3] + bias[p][7] + T::hi(r[3]);
+                    const u32x4 w = pack8<T>(v);
+                    if (in_range(row))
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = w;
                 }
             }
         }
@@ -1717,7 +1757,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
     if (tile == 12 && !g.Bf) tile = 11;
     if (tile == 6 || tile == 8) tile = 7;
-    if (tile == 7 && EPI == SLIME_EPI_BIAS_RESID_F32_LN) tile = 4;     // the 32x32 variant has no LayerNorm-fold epilogue
+    if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
@@ -1742,6 +1782,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
         case SLIME_EPI_BIAS_F32: return launch_epi<T, SLIME_EPI_BIAS_F32>(g, stream);
         case SLIME_EPI_BIAS_RESID_F32: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32>(g, stream);
         case SLIME_EPI_BIAS_RESID_F32_LN: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32_LN>(g, stream);
+        case SLIME_EPI_BIAS_RESID_T: return launch_epi<T, SLIME_EPI_BIAS_RESID_T>(g, stream);
     }
     slime_set_error("gemm: unknown epilogue %d", epi);
     return SLIME_EINVAL;
@@ -1752,7 +1793,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
 extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, int b_frag, char* out, size_t out_len) {
     SLIME_REQUIRE(out && out_len > 0 && M > 0 && N > 0 && K > 0, "gemm_kernel_name: bad input");
     GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr,
-               b_frag ? "" : nullptr, 0};
+               b_frag ? "" : nullptr, 0, nullptr, 0};
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
@@ -1783,11 +1824,14 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     if (a->epilogue == SLIME_EPI_BIAS_RESID_F32_LN)
         SLIME_REQUIRE(a->x16 && a->stats_out && a->ldx >= N && a->ldx % 8 == 0 && ((uintptr_t)a->x16 % 16) == 0 &&
                       ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0, "gemm: BIAS_RESID_F32_LN needs x16 [M, ldx] and stats_out [M, N/64, 2]");
+    if (a->epilogue == SLIME_EPI_BIAS_RESID_T)
+        SLIME_REQUIRE(a->resid && a->ldr >= N && a->ldr % 8 == 0 && ((uintptr_t)a->resid % 16) == 0,
+                      "gemm: BIAS_RESID_T needs resid T [M, ldr >= N] (16-byte aligned, ldr a multiple of 8)");
     // the fragment-order copy of B is optional; it is only usable with whole 64-column tiles, >= 2 k-steps per tile and 32-bit A offsets
     const bool frag_ok = a->B_frag && N % 256 == 0 && ((uintptr_t)a->B_frag % 16) == 0 && (size_t)128 * lda * 2 < (1ull << 32);
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
                a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
-               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl};
+               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);
@@ -1810,7 +1854,8 @@ extern "C" int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* s
 
 extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
                           int M, int N, int K, int dtype, int epilogue, void* stream) {
-    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN, "gemm: BIAS_RESID_F32_LN has extra outputs: use slime_gemm_ex");
+    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN && epilogue != SLIME_EPI_BIAS_RESID_T,
+                  "gemm: BIAS_RESID_F32_LN / BIAS_RESID_T take extra operands: use slime_gemm_ex");
     slime_gemm_args a{};
     a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.dtype = dtype; a.epilogue = epilogue;
     return slime_gemm_ex(&a, stream);

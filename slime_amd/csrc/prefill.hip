@@ -411,13 +411,13 @@ extern "C" size_t slime_llama_attn_workspace_bytes(const slime_llama_attn_desc* 
     return qkv + ctx;
 }
 
-// One implementation behind both entry points: resid == NULL -> out = o_proj(ctx) (T or fp32); else the fused residual form.
+// One implementation behind both entry points: resid == NULL -> out = o_proj(ctx) (T or fp32); else out = T(resid + o_proj(ctx)).
 static int llama_attn_run(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids, const int32_t* kv_start,
-                          const int32_t* kv_len, int batch, int S, void* out, int out_dtype, float* resid, void* next_hidden,
-                          float* next_stats, void* ws, size_t ws_bytes, void* stream) {
+                          const int32_t* kv_len, int batch, int S, void* out, int out_dtype, const void* resid,
+                          void* ws, size_t ws_bytes, void* stream) {
     int rc = llama_validate(d);
     if (rc != SLIME_OK) return rc;
-    SLIME_REQUIRE(hidden && position_ids && batch > 0 && S > 0, "llama_attn: bad input");
+    SLIME_REQUIRE(hidden && position_ids && out && batch > 0 && S > 0, "llama_attn: bad input");
     const size_t need = slime_llama_attn_workspace_bytes(d, batch, S);
     if (!ws || ws_bytes < need || ((uintptr_t)ws % 256) != 0) {
         slime_set_error("llama_attn: workspace %zu B (need %zu, 256-B aligned)", ws_bytes, need);
@@ -443,11 +443,9 @@ static int llama_attn_run(const slime_llama_attn_desc* d, const void* hidden, co
     // o_proj (:92), optionally with the decoder layer's residual add in its epilogue
     ga = slime_gemm_args{};
     ga.A = ctx; ga.lda = HQ * DH; ga.B = d->w_o; ga.B_frag = d->w_o_frag; ga.M = M; ga.N = D; ga.K = HQ * DH; ga.dtype = d->dtype;
-    if (resid) {
-        ga.C = resid; ga.ldc = D; ga.epilogue = SLIME_EPI_BIAS_RESID_F32_LN; ga.x16 = next_hidden; ga.ldx = D; ga.stats_out = next_stats;
-    } else {
-        ga.C = out; ga.ldc = D; ga.epilogue = out_dtype == SLIME_F32 ? SLIME_EPI_BIAS_F32 : SLIME_EPI_BIAS_T;
-    }
+    ga.C = out; ga.ldc = D;
+    if (resid) { ga.epilogue = SLIME_EPI_BIAS_RESID_T; ga.resid = resid; ga.ldr = D; }
+    else ga.epilogue = out_dtype == SLIME_F32 ? SLIME_EPI_BIAS_F32 : SLIME_EPI_BIAS_T;
     return slime_gemm_ex(&ga, stream);
 }
 
@@ -456,14 +454,13 @@ extern "C" int slime_llama_attn_forward(const slime_llama_attn_desc* d, const vo
                                         void* ws, size_t ws_bytes, void* stream) {
     SLIME_REQUIRE(d && out, "llama_attn: bad input");
     SLIME_REQUIRE(out_dtype == d->dtype || out_dtype == SLIME_F32, "llama_attn: out dtype must be the operand type or F32");
-    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, out, out_dtype, nullptr, nullptr, nullptr, ws, ws_bytes, stream);
+    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, out, out_dtype, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int slime_llama_attn_forward_resid(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
-                                              const int32_t* kv_start, const int32_t* kv_len, int batch, int S, float* resid_f32,
-                                              void* next_hidden, float* next_stats, void* ws, size_t ws_bytes, void* stream) {
-    SLIME_REQUIRE(d && resid_f32 && next_hidden && next_stats, "llama_attn_resid: resid_f32, next_hidden and next_stats are required");
-    SLIME_REQUIRE(d->hidden % 64 == 0, "llama_attn_resid: hidden=%d must be a multiple of 64", d->hidden);
-    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, nullptr, d->dtype, resid_f32, next_hidden, next_stats, ws,
-                          ws_bytes, stream);
+                                              const int32_t* kv_start, const int32_t* kv_len, int batch, int S, const void* resid,
+                                              void* out, void* ws, size_t ws_bytes, void* stream) {
+    SLIME_REQUIRE(d && resid && out, "llama_attn_resid: resid and out are required");
+    SLIME_REQUIRE(hidden != out, "llama_attn_resid: out may alias resid, not the layer's input rows");
+    return llama_attn_run(d, hidden, position_ids, kv_start, kv_len, batch, S, out, d->dtype, resid, ws, ws_bytes, stream);
 }

@@ -178,3 +178,51 @@ def sharded_tower_gather(local_feats: torch.Tensor, world: int, group=None) -> t
                       device=local_feats.device)
     dist.all_gather_into_tensor(out, local_feats.contiguous(), group=group)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Head-sharded prefill attention (beyond the crop split north_star names -> opt-in: bench.py --prefill-shard heads)
+# ------------------------------------------------------------------------------------------------------------------------
+# Configs 4 / 5 replicate the 32 attention sub-layers on every rank (Amdahl: ~44 of 60 ms do not shrink with more GPUs).  The
+# natural shard of grouped-query attention is the kv head: rank r owns n_kv_heads / G kv heads and their query heads --
+#   q/k/v GEMM: column slice of the fused [q|k|v] operand (N = 6144 / G at Llama-3-8B), no communication;
+#   RoPE + causal GQA attention: local to the rank's heads;
+#   o_proj: ROW-parallel -- rank r multiplies its ctx slice [M, HQ/G * 128] with the matching 512 columns of W_o and holds a
+#           partial [M, D]; ONE all-reduce (sum) per layer completes it.  The decoder layer's residual is folded into rank 0's
+#           partial (its o_proj epilogue adds it), so the reduced tensor is the next layer's input: no arithmetic outside the
+#           library, one collective per layer.
+# Bytes: the all-reduce moves M * D * 2 B of 16-bit partials per layer (config 5: 9280 x 4096 x 2 = 76 MB; config 4: 80 MB);
+# with RCCL's direct (all-links) algorithm on a fully connected xGMI node every rank sends and receives 2 * (G-1)/G of that over
+# 7 links: ~0.13 ms per layer at 8 GPUs against ~0.22 ms of sharded compute (1.73 ms / 8) -- the exchange is NOT hideable (the
+# next layer's q/k/v GEMM consumes the reduced rows), so the prefill part scales ~4-5x on 8 GPUs instead of 1x (replicated).
+# Numerics: the partial sums are rounded to T before the reduction (standard tensor parallelism): tolerance-equal, not bit-equal,
+# to the replicated result -- which is why the replicated form stays the default until a multi-GPU box has measured both.
+
+def shard_llama_attention_weights(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor, n_heads: int,
+                                  n_kv_heads: int, world: int, rank: int, head_dim: int = 128):
+    """Rank ``rank``'s slice of one attention layer: (wq_r, wk_r, wv_r, wo_r, n_heads_r, n_kv_heads_r).  kv heads are the unit:
+    ``n_kv_heads % world == 0`` (Llama-3-8B: 8 kv heads -> 1 per GPU on a node)."""
+    if n_kv_heads % world != 0 or n_heads % n_kv_heads != 0:
+        raise ValueError(f"{n_kv_heads} kv heads do not split over {world} ranks")
+    kv = n_kv_heads // world
+    grp = n_heads // n_kv_heads
+    qs = slice(rank * kv * grp * head_dim, (rank + 1) * kv * grp * head_dim)
+    ks = slice(rank * kv * head_dim, (rank + 1) * kv * head_dim)
+    return wq[qs], wk[ks], wv[ks], wo[:, qs], kv * grp, kv
+
+
+def head_sharded_attention(local_attn: Callable[[torch.Tensor, "torch.Tensor | None"], torch.Tensor], hidden: torch.Tensor,
+                           resid: torch.Tensor, group=None) -> torch.Tensor:
+    """One decoder-layer attention step over head-sharded weights: ``local_attn(hidden, resid_or_None)`` returns this rank's
+    partial ``[B, S, D]`` (o_proj over the rank's heads; rank 0 is handed ``resid`` and folds it in, the other ranks get None),
+    the all-reduce sums the partials in place.  Returns ``resid + self_attn(hidden)`` on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_attn(hidden, resid)
+    part = local_attn(hidden, resid if dist.get_rank(group) == 0 else None).contiguous()
+    dist.all_reduce(part, op=dist.ReduceOp.SUM, group=group)
+    return part
+
+
+def head_shard_bytes(rows: int, hidden: int = 4096, elem: int = 2) -> int:
+    """Bytes of one layer's all-reduce operand (the 16-bit partial output rows) for the DESIGN.md section 7 table."""
+    return rows * hidden * elem

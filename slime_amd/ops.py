@@ -80,16 +80,18 @@ def pack_b_frag(w: torch.Tensor) -> Optional[torch.Tensor]:
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
-         out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]; w_frag = pack_b_frag(w) (optional)."""
+         out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]; w_frag = pack_b_frag(w) (optional); resid T [M,N] for
+    EPI_BIAS_RESID_T (out = T(a @ w.T + bias + resid), out may be resid)."""
     lib = _lib.load()
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        odt = a.dtype if epilogue <= _lib.EPI_BIAS_GELU_T else torch.float32
+        odt = a.dtype if (epilogue <= _lib.EPI_BIAS_GELU_T or epilogue == _lib.EPI_BIAS_RESID_T) else torch.float32
         out = torch.empty((M, N), dtype=odt, device=a.device)
     g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(out), ldc=out.stride(0), M=M, N=N, K=K,
-                      dtype=dtype_code(a.dtype), epilogue=epilogue, B_frag=_ptr(w_frag))
+                      dtype=dtype_code(a.dtype), epilogue=epilogue, B_frag=_ptr(w_frag), resid=_ptr(resid),
+                      ldr=resid.stride(0) if resid is not None else 0)
     _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return out
 
@@ -817,30 +819,27 @@ def _position_ids(position_ids: Optional[torch.Tensor], B: int, S: int, device) 
 
 
 def llama_attention_forward_resid(pa: PackedLlamaAttention, hidden: torch.Tensor, resid: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
-                                  attention_mask: Optional[torch.Tensor] = None, next_hidden: Optional[torch.Tensor] = None,
-                                  next_stats: Optional[torch.Tensor] = None):
+                                  attention_mask: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The attention sub-layer with the decoder layer's residual add in o_proj's epilogue (slime_llama_attn_forward_resid):
-    ``resid`` fp32 [B, S, D] is updated IN PLACE, ``next_hidden`` T [B, S, D] = T(resid) is what the next layer consumes.
-    Returns (next_hidden, next_stats [B*S, D/64, 2])."""
+    out = T(resid + self_attn(hidden)), all T [B, S, D].  ``out`` may be ``resid`` itself (in-place stream); ``hidden`` may be
+    ``resid`` (no norm in between) but not ``out``."""
     lib = _lib.load()
     _require_cuda(hidden, "hidden")
     B, S, D = hidden.shape
-    assert D == pa.hidden and resid.dtype == torch.float32 and resid.is_contiguous() and tuple(resid.shape) == (B, S, D)
-    x = hidden.to(pa.dtype).contiguous()
+    assert D == pa.hidden and hidden.dtype == pa.dtype and resid.dtype == pa.dtype and tuple(resid.shape) == (B, S, D)
+    x, r = hidden.contiguous(), resid.contiguous()
     pos = _position_ids(position_ids, B, S, x.device)
     start, length = token_ranges(None if attention_mask is None else attention_mask.to(x.device))
-    if next_hidden is None:
-        next_hidden = torch.empty((B, S, D), dtype=pa.dtype, device=x.device)
-    if next_stats is None:
-        next_stats = torch.empty((B * S, D // 64, 2), dtype=torch.float32, device=x.device)
-    assert next_hidden.data_ptr() != x.data_ptr(), "the layer's input rows are read by its own q/k/v GEMM only, but keep two buffers"
+    if out is None:
+        out = torch.empty((B, S, D), dtype=pa.dtype, device=x.device)
+    assert out.is_contiguous() and out.dtype == pa.dtype and out.data_ptr() != x.data_ptr()
     need = lib.slime_llama_attn_workspace_bytes(C.byref(pa.desc), B, S)
     ws = pa.ws.get(need, x.device)
     base = (ws.data_ptr() + 255) // 256 * 256
     _lib.check(lib.slime_llama_attn_forward_resid(C.byref(pa.desc), x.data_ptr(), pos.data_ptr(), _ptr(start), _ptr(length), B, S,
-                                                  resid.data_ptr(), next_hidden.data_ptr(), next_stats.data_ptr(), base,
-                                                  ws.numel() - (base - ws.data_ptr()), _stream()), "slime_llama_attn_forward_resid")
-    return next_hidden, next_stats
+                                                  r.data_ptr(), out.data_ptr(), base, ws.numel() - (base - ws.data_ptr()), _stream()),
+               "slime_llama_attn_forward_resid")
+    return out
 
 
 def llama_attention_forward(pa: PackedLlamaAttention, hidden: torch.Tensor, position_ids: Optional[torch.Tensor] = None,

@@ -95,3 +95,68 @@ def test_gather_bytes_table():
     assert 0.25 < comp / full < 0.35
     full, comp = gather_bytes(320, 5, 8)
     assert comp / full < 0.45
+
+
+def _head_shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from slime_amd.dist import shard_llama_attention_weights, head_sharded_attention
+        from oracle import prefill_oracle as P
+        torch.set_num_threads(2)
+        D, HQ, HKV, B, S = 1024, 8, 4, 2, 37
+        g = torch.Generator().manual_seed(17)
+        w = [torch.randn(n, k, generator=g) * k ** -0.5 for n, k in ((HQ * 128, D), (HKV * 128, D), (HKV * 128, D), (D, HQ * 128))]
+        hidden = torch.randn(B, S, D, generator=g)
+        resid = torch.randn(B, S, D, generator=g)
+        mask = torch.ones(B, S, dtype=torch.int64)
+        mask[1, 30:] = 0
+        pos = torch.arange(S)[None].expand(B, S)
+        full = resid + P.llama_attention_forward(hidden, w[0], w[1], w[2], w[3], HQ, HKV, pos, mask)
+        wq, wk, wv, wo, hq_r, hkv_r = shard_llama_attention_weights(w[0], w[1], w[2], w[3], HQ, HKV, world, rank)
+        calls = []
+
+        def local(h, r):
+            calls.append(r is not None)
+            part = P.llama_attention_forward(h, wq, wk, wv, wo, hq_r, hkv_r, pos, mask, head_dim=128)       # the oracle as the rank-local kernel
+            return part + r if r is not None else part
+
+        got = head_sharded_attention(local, hidden, resid)
+        err = float((got - full).norm() / full.norm())
+        ok = err < 1e-5 and calls == [rank == 0] and hq_r == HQ // world and hkv_r == HKV // world
+        ok = ok and tuple(wq.shape) == (HQ // world * 128, D) and tuple(wo.shape) == (D, HQ // world * 128)
+        q.put((rank, bool(ok), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_sharded_prefill_attention_world2():
+    """kv-head sharding of the Llama attention sub-layer (column-sliced q/k/v, local causal GQA, row-parallel
+    o_proj + one all-reduce, residual folded into rank 0's partial) equals the replicated result to fp32 rounding.  The oracle
+    stands in for the rank-local HIP call (checker of the sharding code, not a product path)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_head_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_head_shard_weight_slices_cover_the_layer():
+    from slime_amd.dist import shard_llama_attention_weights, head_shard_bytes
+    HQ, HKV, D = 32, 8, 256
+    wq, wk, wv, wo = torch.arange(HQ * 128 * D).view(HQ * 128, D), torch.arange(HKV * 128 * D).view(HKV * 128, D), \
+        -torch.arange(HKV * 128 * D).view(HKV * 128, D), torch.arange(D * HQ * 128).view(D, HQ * 128)
+    for world in (1, 2, 4, 8):
+        parts = [shard_llama_attention_weights(wq, wk, wv, wo, HQ, HKV, world, r) for r in range(world)]
+        assert torch.equal(torch.cat([p[0] for p in parts]), wq) and torch.equal(torch.cat([p[1] for p in parts]), wk)
+        assert torch.equal(torch.cat([p[2] for p in parts]), wv) and torch.equal(torch.cat([p[3] for p in parts], 1), wo)
+        assert all(p[4] == HQ // world and p[5] == HKV // world for p in parts)
+    with pytest.raises(ValueError):
+        shard_llama_attention_weights(wq, wk, wv, wo, HQ, HKV, 3, 0)
+    assert head_shard_bytes(9280) == 9280 * 4096 * 2

@@ -71,6 +71,13 @@ def _check_all_epilogues(dev, dtype, M, N, K):
     h0 = h.clone()
     ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=h)
     assert rel_l2(h, h0 + ref) < TOL_F32
+    # 16-bit residual stream (Llama decoder layer): T(acc + bias + resid), also in place (out aliases resid)
+    r = _rand((M, N), dtype, dev, 5, 2.0)
+    out = ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_T, resid=r)
+    assert out.dtype == dtype and rel_l2(out.float(), ref + r.float()) < TOL_T[dtype]
+    r2 = r.clone()
+    ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_T, out=r2, resid=r2)
+    assert torch.equal(r2, out)
 
 
 # The tower's production launch shapes (20-crop half batch M = 11540; the stacked adapter MLP M = 13824), AUTO dispatch of the
@@ -132,6 +139,14 @@ def _check_direct_b(dev, dtype, M, N, K, forced):
             assert torch.equal(got, ops.gemm(a, w, bias, epi)), f"epilogue {epi}: differs from the LDS-staged kernel"
     got = ops.gemm(a, w, None, _lib.EPI_BIAS_F32, w_frag=wf)
     assert rel_l2(got, ref - bias) < TOL_F32
+    r = _rand((M, N), dtype, dev, 5, 2.0)
+    got = ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_T, w_frag=wf, resid=r)
+    assert rel_l2(got.float(), ref + r.float()) < TOL_T[dtype]
+    if not forced:
+        assert torch.equal(got, ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_T, resid=r))
+    r2 = r.clone()
+    ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_T, out=r2, w_frag=wf, resid=r2)
+    assert torch.equal(r2, got)
     # residual update, plain and as LayerNorm-fold producer
     h0 = _rand((M, N), torch.float32, dev, 4, 2.0) + 0.3
     h1, h2, h3 = h0.clone(), h0.clone(), h0.clone()

@@ -341,15 +341,16 @@ def test_llama_attention_real_size_vs_oracle(dev, llama8b_case, dtype):
     worst = ((out - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-6))[mask.bool()].max()
     assert float(worst) < 6 * TOL[dtype]
     assert float(out[mask == 0].abs().max()) == 0.0
-    # the fused-residual form (decoder layer's residual add in o_proj's epilogue): fp32 stream bit-equal to resid + out,
-    # next_hidden = T(resid), partial sums of the updated rows
-    resid0 = torch.randn(B, S, D, generator=torch.Generator().manual_seed(3)).to(dev)
-    resid = resid0.clone()
-    nxt, stats = ops.llama_attention_forward_resid(pa, hidden.to(dev), resid, pos.to(dev), mask.to(dev))
-    assert torch.equal(resid, resid0 + out.to(dev))
-    assert torch.equal(nxt, resid.to(dtype))
-    r = resid.view(B * S, D // 64, 64)
-    assert rel_l2(stats[..., 0], r.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (r * r).sum(-1)) < 1e-5
+    # the fused-residual form (decoder layer's residual add in o_proj's epilogue, 16-bit stream as in HF):
+    # out = T(resid + attn) with ONE rounding -- equal to rounding (resid + fp32 attention output) once
+    hid_t = hidden.to(dev).to(dtype)
+    resid = (torch.randn(B, S, D, generator=torch.Generator().manual_seed(3)) * 2).to(dtype).to(dev)
+    out32 = ops.llama_attention_forward(pa, hid_t, pos.to(dev), mask.to(dev), torch.float32)
+    fused = ops.llama_attention_forward_resid(pa, hid_t, resid, pos.to(dev), mask.to(dev))
+    assert fused.dtype == dtype and torch.equal(fused, (resid.float() + out32).to(dtype))
+    inplace = resid.clone()
+    ops.llama_attention_forward_resid(pa, hid_t, inplace, pos.to(dev), mask.to(dev), out=inplace)      # out aliases resid
+    assert torch.equal(inplace, fused)
 
 
 @pytest.mark.parametrize("form", ["row", "vector", "none"])
