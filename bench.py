@@ -488,6 +488,7 @@ def build_prefill(enc, dev, dt, n_images, visual_rows, text_tokens=64, layers=32
     def kernel_times():
         lib, st = ops._lib.load(), torch.cuda.current_stream().cuda_stream
         p = packs[0]
+        HQ, HKV = p.n_heads, p.n_kv_heads                    # this rank's heads (all of them unless --prefill-shard heads)
         N = (HQ + 2 * HKV) * 128
         qkv = (torch.randn(images, S, N, device=dev) * 0.3).to(dt)
         o = torch.empty((images, S, HQ * 128), dtype=dt, device=dev)

@@ -274,6 +274,12 @@ int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels, int pix_dt
                          void* out, int out_dtype, int keep_cls, float* hidden_f32,
                          void* ws, size_t ws_bytes, void* stream, const slime_probe* probe);
 
+/* All hidden states of ONE pass (HF CLIPVisionModel(..., output_hidden_states=True), which CLIPVisionTower.forward requests,
+ * clip_encoder.py:51,55): states_f32 [layers_run + 1, n, 1 + P, hidden] fp32 -- entry 0 = embeddings after pre_layrnorm,
+ * entry i = output of encoder layer i.  Run with a descriptor whose layers_run covers the last state wanted. */
+int slime_vit_forward_states(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n_crops, float* states_f32,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Resampler (sampler.py:91-173) with kv_proj = proj = Identity, as post_qformer / GatedBlock.attn
  * ---------------------------------------------------------------------------------------------- */

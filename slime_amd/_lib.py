@@ -114,6 +114,7 @@ _SIGNATURES = {
                                   c_size_t, c_void_p]),
     "slime_vit_forward_ex": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                      c_size_t, c_void_p, _P(Probe)]),
+    "slime_vit_forward_states": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "slime_resampler_workspace_bytes": (c_size_t, [_P(ResamplerDesc), c_int]),
     "slime_resampler_forward": (c_int, [_P(ResamplerDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_size_t, c_void_p]),

@@ -107,12 +107,26 @@ static constexpr int g_vit_skip_mask = 0;
         if (on_ && probe->stop) (void)hipEventRecord((hipEvent_t)probe->stop, (hipStream_t)stream);          \
     } while (0)
 
+static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out, int out_dtype, int keep_cls,
+                   float* hidden_f32, void* ws, size_t ws_bytes, void* stream, const slime_probe* probe, float* states);
+
 extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out,
                                     int out_dtype, int keep_cls, float* hidden_f32, void* ws, size_t ws_bytes,
                                     void* stream, const slime_probe* probe) {
+    return vit_run(d, pixels, pix_dtype, n, out, out_dtype, keep_cls, hidden_f32, ws, ws_bytes, stream, probe, nullptr);
+}
+
+extern "C" int slime_vit_forward_states(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, float* states_f32,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    SLIME_REQUIRE(states_f32, "vit_forward_states: states_f32 is required");
+    return vit_run(d, pixels, pix_dtype, n, nullptr, SLIME_F32, 1, nullptr, ws, ws_bytes, stream, nullptr, states_f32);
+}
+
+static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, int n, void* out, int out_dtype, int keep_cls,
+                   float* hidden_f32, void* ws, size_t ws_bytes, void* stream, const slime_probe* probe, float* states) {
     TRY(vit_validate(d));
     SLIME_REQUIRE(pixels && n > 0, "vit: bad input");
-    SLIME_REQUIRE(out || hidden_f32, "vit: no output requested");
+    SLIME_REQUIRE(out || hidden_f32 || states, "vit: no output requested");
     SLIME_REQUIRE(!out || out_dtype == SLIME_F32 || is16(out_dtype), "vit: bad out dtype");
     const VitPlan p = vit_plan(d, n);
     if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
@@ -139,6 +153,14 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
     TRY(slime_gemm(a_pe, d->kpad, d->patch_w, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
     TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, d->layers_run > 0 ? xn : nullptr,
                             d->layers_run > 0 ? stats : nullptr, dt, n, P, D, stream));
+    // hidden_states[i] of HF's output_hidden_states=True (entry 0 = the pre-LayerNorm'd embeddings, entry i = after layer i):
+    // a device-to-device copy of the fp32 residual stream on the call's stream (capturable), one per state
+#define SNAPSHOT(idx)                                                                                                           \
+    do {                                                                                                                        \
+        if (hipMemcpyAsync(states + (size_t)(idx) * M * D, h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice,         \
+                           (hipStream_t)stream) != hipSuccess) { slime_set_error("vit: hidden-state snapshot failed"); return SLIME_ELAUNCH; } \
+    } while (0)
+    if (states) SNAPSHOT(0);
 
     // Layer loop, 5 launches per layer.  Both LayerNorms are FOLDED into the GEMMs around them (slime_gemm_ex): the GEMM that
     // updates the residual stream (previous fc2 / out_proj, or the embedding kernel) leaves the rows rounded to T (`xn`) and
@@ -185,6 +207,7 @@ extern "C" int slime_vit_forward_ex(const slime_vit_desc* d, const void* pixels,
         if (!last) { ga.x16 = xn; ga.ldx = D; ga.stats_out = stats; }
         ga.B_frag = frag(d->w_fc2_frag, (size_t)D * F);
         PROBED(6, slime_gemm_ex(&ga, stream));
+        if (states) SNAPSHOT(l + 1);
     }
     if (out) {
         // feature_select: 'patch' drops the class token (clip_encoder.py:38-39), cast to out dtype (:52,56)

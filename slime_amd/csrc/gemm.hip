@@ -947,19 +947,26 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 // VMEM requests younger than weight request G_nj of the PREVIOUS k-step at the moment MFMA group nj of the current one starts
-constexpr int db_younger(int nj, bool prev_dma, bool cur_dma, bool cur_gl) {
+// (mi = 16-row MFMA tiles per wave: DMA piece j of the wave's mi/2 follows MFMA mi*j + mi/2 - 1, request G_nj follows MFMA mi*nj + mi - 1)
+constexpr int db_younger(int mi, int nj, bool prev_dma, bool cur_dma, bool cur_gl) {
     int c = (3 - nj) + (cur_gl ? nj : 0);
-    for (int j = 0; j < 4; ++j) {
-        const int pos = 8 * j + 3;
-        if (prev_dma && pos > 8 * nj + 7) ++c;
-        if (cur_dma && pos < 8 * nj) ++c;
+    for (int j = 0; j < mi / 2; ++j) {
+        const int pos = mi * j + mi / 2 - 1;
+        if (prev_dma && pos > mi * nj + mi - 1) ++c;
+        if (cur_dma && pos < mi * nj) ++c;
     }
     return c;
 }
 
-template <typename T, int EPI, int KTAG>
+// MI = 8: 128 x 256 tile, two workgroups per CU (the product form).  MI = 4: 64 x 256 tile (64 accumulators), built into the diagnostic
+// library only (tile 13): tried for grids that do not give every CU a 128-row workgroup (rank shards of 5-9 crops, single images) and
+// measured SLOWER than the 128 x 128 lock-step kernel there (tower over 5 crops 3.70 -> 3.95 ms with fc2 on it, 9 crops 4.84 -> 5.07;
+// profiles/r03_small_batch_latency_b.txt): a 16-MFMA k-step (270 cycles) is shorter than the latency of the weight fragments
+// requested one k-step ahead, and an under-filled chip has no second wave per SIMD to cover it.
+template <typename T, int EPI, int KTAG, int MI>
 __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
-    constexpr int MI = 8, NJ = 4, BM = 128, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = 4;
+    constexpr int NJ = 4, BM = 16 * MI, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = MI / 2;
+    static_assert(MI == 8 || MI == 4, "direct-B tile heights: 128 or 64 rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
@@ -969,7 +976,7 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
         const int b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
-    const int GROUP_M = g.group_m > 0 ? g.group_m : 8;
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 1024 / BM;
     const int in_group = GROUP_M * tiles_n;
     const int first_m = (pid / in_group) * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -1042,13 +1049,13 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
         constexpr bool PD = decltype(prev_dma)::value, D = decltype(dmas)::value, G = decltype(gls)::value, R = decltype(reads)::value;
         static_for<0, NJ>([&](auto njc) {
             constexpr int nj = decltype(njc)::value;
-            vm_wait_frag<db_younger(nj, PD, D, G)>(FB[nj]);
+            vm_wait_frag<db_younger(MI, nj, PD, D, G)>(FB[nj]);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = MI * nj + mi;
                 T::mfma16_agpr(acc[mi][nj], FB[nj], cur[mi]);
                 if constexpr (R) { if (m % 4 == 1) read_frag(nxt[m / 4], m / 4, xbase_next); }
-                if constexpr (D) { if (m % 8 == 3) dma(m / 8, dma_tile); }
+                if constexpr (D) { if (m % MI == MI / 2 - 1 && m / MI < AP) dma(m / MI, dma_tile); }
                 if constexpr (G) { if (mi == MI - 1) gl(njc, next_kstep); }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1666,18 +1673,19 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 
-template <typename T, int EPI, int KTAG>
+template <typename T, int EPI, int KTAG, int MI>
 static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
-    constexpr int LDS = 2 * 128 * 64 * 2 + 128 * 8;                 // two A stages + the LayerNorm-fold row table
-    auto kern = gemm_db_kernel<T, EPI, KTAG>;
-    const int tiles_m = (g.M + 127) / 128, tiles_n = g.N / 256;
+    constexpr int BM = 16 * MI;
+    constexpr int LDS = 2 * BM * 64 * 2 + BM * 8;                   // two A stages + the LayerNorm-fold row table
+    auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_db");
     return SLIME_OK;
 }
-template <typename T, int EPI>
+template <typename T, int EPI, int MI>
 static int launch_db(const GemmArgs& g, hipStream_t stream) {
-    return g.K >= 2048 ? launch_db_k<T, EPI, 1>(g, stream) : launch_db_k<T, EPI, 0>(g, stream);
+    return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI>(g, stream) : launch_db_k<T, EPI, 0, MI>(g, stream);
 }
 
 template <typename T, int EPI>
@@ -1755,7 +1763,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
-    if (tile == 12 && !g.Bf) tile = 11;
+    if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 12 ? 11 : 3;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
@@ -1766,7 +1774,12 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
     if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
 #endif
-    if (tile == 12) return launch_db<T, EPI>(g, stream);
+    if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
+#ifdef SLIME_DIAG
+    if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
+#else
+    if (tile == 13) return launch_db<T, EPI, 8>(g, stream);
+#endif
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
     if (tile == 11) return launch_w4<T, EPI, 8>(g, stream);
@@ -1797,7 +1810,7 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
-    if (tile == 12) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d>", t, epilogue, ktag);
+    if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
     else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
     else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, 1>", t, epilogue);

@@ -152,13 +152,16 @@ class HipCLIPVisionModel(nn.Module):
             cur.wait_stream(s)
         return out
 
+    @torch.no_grad()
     def forward(self, pixel_values: torch.Tensor, output_hidden_states: bool = False, **_):
-        """HF-like call: returns an object with ``hidden_states`` (L+1 entries, computed on demand is
-        not possible for a tuple, so all requested states are produced by separate tower runs --
-        use :meth:`encode` on the hot path) and ``last_hidden_state``."""
+        """HF-like call: returns an object with ``hidden_states`` (L+1 entries: embeddings after pre_layrnorm, then the output
+        of every layer -- ONE tower pass over all L layers that snapshots the fp32 residual stream after each,
+        ``slime_vit_forward_states``; use :meth:`encode` on the hot path, which runs only the layers its state needs) and
+        ``last_hidden_state`` (HF: hidden_states[-1], without post_layernorm)."""
         L = self.config.num_hidden_layers
         if output_hidden_states:
-            hs = tuple(self.encode(pixel_values, i, keep_cls=True) for i in range(L + 1))
+            st = ops.tower_hidden_states(self.packed(L), pixel_values).to(pixel_values.dtype)
+            hs = tuple(st[i] for i in range(L + 1))
             return SimpleNamespace(hidden_states=hs, last_hidden_state=hs[-1])
         return SimpleNamespace(hidden_states=None, last_hidden_state=self.encode(pixel_values, L, keep_cls=True))
 

@@ -292,6 +292,26 @@ def tower_forward(pt: PackedTower, pixels: torch.Tensor, out_dtype: Optional[tor
     return (out, hidden) if want_hidden else out
 
 
+def tower_hidden_states(pt: PackedTower, pixels: torch.Tensor) -> torch.Tensor:
+    """pixels [N,3,S,S] -> fp32 [layers_run + 1, N, 1 + P, D]: every hidden state of ONE tower pass (slime_vit_forward_states)."""
+    lib = _lib.load()
+    _require_cuda(pixels, "pixels")
+    cfg = pt.cfg
+    if pixels.dim() != 4 or pixels.shape[1] != 3 or pixels.shape[2] != cfg.image_size or pixels.shape[3] != cfg.image_size:
+        raise ValueError(f"Input image size ({tuple(pixels.shape[2:])}) doesn't match model ({cfg.image_size}*{cfg.image_size}).")
+    if pixels.dtype not in (torch.float32, pt.dtype):
+        pixels = pixels.to(pt.dtype)
+    pixels = pixels.contiguous()
+    n = pixels.shape[0]
+    states = torch.empty((pt.layers_run + 1, n, cfg.seq_len, cfg.hidden_size), dtype=torch.float32, device=pixels.device)
+    need = lib.slime_vit_workspace_bytes(C.byref(pt.desc), n)
+    ws = pt.ws.get(need, pixels.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    _lib.check(lib.slime_vit_forward_states(C.byref(pt.desc), pixels.data_ptr(), dtype_code(pixels.dtype), n, states.data_ptr(), base,
+                                            ws.numel() - (base - ws.data_ptr()), _stream()), "slime_vit_forward_states")
+    return states
+
+
 def gemm_kernel_name(M: int, N: int, K: int, dtype: torch.dtype, epilogue: int, has_b_frag: bool = False) -> str:
     lib = _lib.load()
     buf = C.create_string_buffer(128)

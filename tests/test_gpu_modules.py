@@ -71,6 +71,14 @@ def test_vision_tower_module(dev, dtype):
     hs = tower.vision_tower(px[:1].to(dev), output_hidden_states=True).hidden_states
     assert len(hs) == W.TINY.num_hidden_layers + 1
     assert torch.equal(tower.feature_select(SimpleNamespace(hidden_states=hs)).cpu(), tower(px[:1].to(dev)).cpu())
+    # ONE pass produces all L+1 states (slime_vit_forward_states): each against the oracle's hidden_states list, and the
+    # last one equals the separate full-depth run bit for bit
+    ref_hs = O.clip_hidden_states(tsd, W.TINY, px[:1])
+    assert all(h.shape == (1, 577, 128) and h.dtype == torch.float32 for h in hs)
+    for i, h in enumerate(hs):
+        assert rel_l2(h.cpu(), ref_hs[i]) < TOL[dtype] * 1.5, i
+    last = tower.vision_tower(px[:1].to(dev)).last_hidden_state
+    assert torch.equal(last, hs[-1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

@@ -59,8 +59,9 @@ for n in (5, 9, 10, 17, 20):
     print(f"{n} crops: " + "  ".join(f"{k} {v['us']} us ({v['tflops']} TF/s)" for k, v in rec.items()), file=sys.stderr, flush=True)
 # sub-round grids: LDS-staged auto choice (128x128 / ping-pong) vs the direct-B kernel forced per shape
 out["forced_direct_b_ms"] = {}
-RULES = {"auto": {}, "fc2->db": {(1024, 4096): 12}, "fc2,out->db": {(1024, 4096): 12, (1024, 1024): 12},
-         "all->db": {(1024, 4096): 12, (1024, 1024): 12, (3072, 1024): 12, (4096, 1024): 12}}
+SH4 = [(1024, 4096), (1024, 1024), (3072, 1024), (4096, 1024)]
+RULES = {"auto": {}, "fc2->db64": {SH4[0]: 13}, "fc2,out->db64": {SH4[0]: 13, SH4[1]: 13}, "all->db64": {k: 13 for k in SH4},
+         "fc2,out->db64 qkv,fc1->db128": {SH4[0]: 13, SH4[1]: 13, SH4[2]: 12, SH4[3]: 12}, "all->db128": {k: 12 for k in SH4}}
 for n in (1, 2, 3, 5, 9, 10, 12, 17, 20):
     x = px[:n].contiguous()
     row = {}
