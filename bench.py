@@ -46,7 +46,7 @@ GF_VIT_PER_CROP = 366.034              # live ViT path, 23 layer
 GF_GLOBAL_PER_IMAGE = 54.512           # gated adapter on the global view
 GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-PMC_FILE = "r02_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
+PMC_FILE = "r03_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
 
 CONFIGS = {                            # images per step, local crops per image, local grid
     2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
@@ -189,7 +189,7 @@ def pmc_traffic(rocprof_name):
     the bench line says so in `traffic_source`; null if the kernel is not in the committed summary."""
     pmc = os.path.join(ROOT, "profiles", PMC_FILE)
     if not os.path.isfile(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_kernels.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_kernels.json")
     try:
         rec = json.load(open(pmc)).get(rocprof_name, {})
         if "hbm_read_bytes_corrected" in rec and "hbm_write_bytes" in rec:

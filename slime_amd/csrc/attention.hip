@@ -974,13 +974,22 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
                (char*)o, o_bs, o_rs, heads, n_q, n_kv, 0, g_attn_dbg, g_attn_abl};
     hipStream_t s = (hipStream_t)stream;
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 0 && !g_attn_dbg) {
-        // CLIP shape: software-pipelined kernel, one workgroup per (crop, head), K/V staged once (granule DMA)
+        // CLIP shape: software-pipelined kernel, one or two workgroups per (crop, head), K/V staged once (granule DMA).
+        // Round 3 re-measured the one-wave-per-SIMD alternative (attention32.inc, diagnostic variants 4-6) now that the GEMMs run two
+        // workgroups per CU: its uncut form is worth 1 % of the 40-crop tower (15.18 -> 15.01 ms, profiles/r03_tower_knobs.txt) but
+        // costs 0.25 ms per pass at <= 8 crops (27 instead of 18 us per launch), and its cut forms, which fix that, change the last
+        // bit of some rows with the cut -- the sharded tower must reproduce the 1-GPU tensor bit for bit at every shard size.  It
+        // stays a measured alternative.
         if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
         return launch_attn64r<BF16>(a, batch, s);
     }
 #ifdef SLIME_DIAG
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant >= 4 && g_attn_variant <= 6 && dtype == SLIME_BF16)
         return launch_attn32<BF16>(a, batch, g_attn_variant == 5 ? 2 : g_attn_variant == 6 ? -1 : 0, s);
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 7 && !g_attn_dbg) {    // round 2's product kernel, for A/B
+        if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
+        return launch_attn64r<BF16>(a, batch, s);
+    }
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 3 && !g_attn_dbg) {
         if (dtype == SLIME_F16) return launch_attn64w<F16>(a, batch, s);
         return launch_attn64w<BF16>(a, batch, s);

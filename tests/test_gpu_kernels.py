@@ -453,7 +453,6 @@ def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
     assert rel_l2(out.float().cpu(), ref.cpu()) < TOL_T[dtype] * 1.5   # + P rounded to T before PV
 
 
-@pytest.mark.parametrize("variant", [4, 5, 6])
 @pytest.mark.parametrize("B,heads,nq,nkv,gain", [
     (2, 2, 577, 577, 1.0),      # CLIP geometry: 19 query blocks -> 5,5,5,4 per wave; ragged last key step (one live key)
     (3, 4, 577, 577, 12.0),     # logits with std 12: the speculative softmax is thrown away and recomputed many times
@@ -464,10 +463,12 @@ def test_attention(dev, dtype, B, heads, dh, nq, nkv, shared_q):
     (2, 2, 300, 577, 6.0),      # 10 blocks -> 3,3,2,2
     (17, 16, 577, 577, 1.0),    # 272 (crop, head) items: one round of 256 uncut + 16 cut by query blocks
 ])
-def test_attention32_alternative(dev, variant, B, heads, nq, nkv, gain):
-    """The measured alternative of the CLIP attention kernel (one wave per SIMD, 32x32x16 MFMAs, hand-placed softmax stream;
-    DESIGN.md section 6), reachable through the DIAGNOSTIC build's variant hook only: 4 = tail cutting, 5 = every item cut in two,
-    6 = uncut.  Same bar as the product kernel, plus a spiked key (the runaway path late in the sweep)."""
+def test_attention32_launch_forms(dev, B, heads, nq, nkv, gain):
+    """attn32 (one wave per SIMD, 32x32x16 MFMAs, hand-placed softmax stream), the measured alternative of
+    the CLIP attention kernel in the DIAGNOSTIC build: 4 = tail cutting, 5 = every item cut in two, 6 = uncut.  Same bar as the
+    product kernel (0 = 7 = attn64r), plus a spiked key (the runaway path late in the sweep).  Recorded here because it decides
+    what can ship: the cut forms do NOT reproduce the uncut form bit for bit (round 3), so a batch-size dependent cut would
+    break the tower's shard invariance."""
     from slime_amd import ops, _lib
     E = heads * 64
     qkv = _rand((B, max(nq, nkv), 3 * E), torch.bfloat16, dev, 50)
@@ -476,15 +477,19 @@ def test_attention32_alternative(dev, variant, B, heads, nq, nkv, gain):
         qkv[0, 500, E:2 * E] = (qkv[0, 17, :E].float() * 60.0 / gain).to(torch.bfloat16)
     q, k, v = qkv[:, :nq, :E], qkv[:, :nkv, E:2 * E], qkv[:, :nkv, 2 * E:]
     ref = _attn_ref(q, k, v, heads, 64)
+    outs = {}
     with _lib.diag() as lib:
-        lib.slime_attention_set_variant(variant)
         try:
-            out = ops.attention(q, k, v, heads, 64)
-            torch.cuda.synchronize()
+            for variant in (0, 4, 5, 6, 7):
+                lib.slime_attention_set_variant(variant)
+                outs[variant] = ops.attention(q, k, v, heads, 64)
+                torch.cuda.synchronize()
         finally:
             lib.slime_attention_set_variant(0)
-    assert torch.isfinite(out.float()).all()
-    assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3
+    for variant, out in outs.items():
+        assert torch.isfinite(out.float()).all(), variant
+        assert rel_l2(out.float().cpu(), ref.cpu()) < 6e-3, variant
+    assert torch.equal(outs[7], outs[0]) and torch.equal(outs[0], ops.attention(q, k, v, heads, 64))       # the product kernel
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

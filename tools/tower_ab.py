@@ -24,9 +24,9 @@ def timed(n=8):
     for _ in range(n): run()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 what = sys.argv[1] if len(sys.argv) > 1 else "attn"
-cases = {"attn": [("attn64r", lambda: lib.slime_attention_set_variant(0)), ("attn64 (r1)", lambda: lib.slime_attention_set_variant(2)),
+cases = {"attn": [("attn64r", lambda: lib.slime_attention_set_variant(7)), ("attn64 (r1)", lambda: lib.slime_attention_set_variant(2)),
                   ("attn64w 12wave", lambda: lib.slime_attention_set_variant(3))],
-         "attn32": [("attn64r", lambda: lib.slime_attention_set_variant(0)), ("attn32", lambda: lib.slime_attention_set_variant(4)),
+         "attn32": [("attn64r", lambda: lib.slime_attention_set_variant(7)), ("attn32", lambda: lib.slime_attention_set_variant(4)),
                     ("attn32 uncut", lambda: lib.slime_attention_set_variant(6))]}[what]
 for _ in range(3): run()
 for rnd in range(4):
