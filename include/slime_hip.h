@@ -252,6 +252,7 @@ typedef struct {
     const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                                   */
     /* optional fragment-order copies of the four per-layer weights (slime_gemm_pack_b per layer, same layer stride), or NULL */
     const void*  w_qkv_frag; const void* w_o_frag; const void* w_fc1_frag; const void* w_fc2_frag;
+    const void*  patch_w_frag;              /* the same for patch_w [hidden, kpad], or NULL                                   */
 } slime_vit_desc;
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);

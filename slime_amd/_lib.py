@@ -37,7 +37,7 @@ class VitDesc(C.Structure):
                 ("w_qkv", c_void_p), ("b_qkv", c_void_p), ("colsum_qkv", c_void_p),
                 ("w_o", c_void_p), ("b_o", c_void_p),
                 ("w_fc1", c_void_p), ("b_fc1", c_void_p), ("colsum_fc1", c_void_p), ("w_fc2", c_void_p), ("b_fc2", c_void_p),
-                ("w_qkv_frag", c_void_p), ("w_o_frag", c_void_p), ("w_fc1_frag", c_void_p), ("w_fc2_frag", c_void_p)]
+                ("w_qkv_frag", c_void_p), ("w_o_frag", c_void_p), ("w_fc1_frag", c_void_p), ("w_fc2_frag", c_void_p), ("patch_w_frag", c_void_p)]
 
 
 class GemmArgs(C.Structure):

@@ -150,7 +150,7 @@ static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, i
 
     // patch embed (conv as GEMM), class token, position table, pre-LayerNorm (which also prepares layer 0's folded LN1)
     TRY(slime_im2col(pixels, pix_dtype, a_pe, n, d->image, d->patch, d->kpad, dt, stream));
-    TRY(slime_gemm(a_pe, d->kpad, d->patch_w, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
+    TRY(gemm_w(a_pe, d->kpad, d->patch_w, d->patch_w_frag, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
     TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, d->layers_run > 0 ? xn : nullptr,
                             d->layers_run > 0 ? stats : nullptr, dt, n, P, D, stream));
     // hidden_states[i] of HF's output_hidden_states=True (entry 0 = the pre-LayerNorm'd embeddings, entry i = after layer i):

@@ -249,11 +249,12 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
         # fragment-order copies for the direct-B GEMM kernel (None at geometries it does not serve: the descriptor field stays NULL)
         for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
             T[name + "_frag"] = pack_b_frag(T[name])
+    T["patch_w_frag"] = pack_b_frag(T["patch_w"])
     d = _lib.VitDesc()
     d.hidden, d.inter, d.heads, d.layers_run = D, Fi, cfg.num_attention_heads, L
     d.image, d.patch, d.kpad, d.dtype, d.eps = cfg.image_size, cfg.patch_size, kpad, dtype_code(dtype), cfg.layer_norm_eps
     for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "w_qkv", "b_qkv", "colsum_qkv", "w_o", "b_o",
-                 "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2", "w_qkv_frag", "w_o_frag", "w_fc1_frag", "w_fc2_frag"):
+                 "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2", "w_qkv_frag", "w_o_frag", "w_fc1_frag", "w_fc2_frag", "patch_w_frag"):
         setattr(d, name, T[name].data_ptr() if name in T and T[name] is not None else None)
     return PackedTower(cfg, dtype, L, T, d)
 

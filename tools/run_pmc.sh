@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 ( timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$R/gpurun_out/prof_pmc_fetch" -- python "$R/tools/pmc_target.py" ) > "$R/gpurun_out/p_pmc_fetch.log" 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$R/gpurun_out/prof_pmc_write" -- python "$R/tools/pmc_target.py" ) > "$R/gpurun_out/p_pmc_write.log" 2>&1
 cd "$R"
-python tools/summarize_prof.py gpurun_out r02 > gpurun_out/p_pmc_summary.log 2>&1
+python tools/summarize_prof.py gpurun_out r03 > gpurun_out/p_pmc_summary.log 2>&1
 tail -3 gpurun_out/p_pmc_sq.log | cut -c1-200; tail -5 gpurun_out/p_pmc_summary.log | cut -c1-300
 find gpurun_out/prof_pmc_sq gpurun_out/prof_pmc_fetch gpurun_out/prof_pmc_write -name "*kernel_trace.csv" -delete
-ls gpurun_out | head -30
+cp profiles/r03_pmc_kernels.json gpurun_out/z_r03_pmc_kernels.json; cp profiles/r03_pmc_summary.json gpurun_out/z_r03_pmc_summary.json; rm -rf gpurun_out/prof_pmc_*
