@@ -467,8 +467,9 @@ def test_attention32_launch_forms(dev, B, heads, nq, nkv, gain):
     """attn32 (one wave per SIMD, 32x32x16 MFMAs, hand-placed softmax stream), the measured alternative of
     the CLIP attention kernel in the DIAGNOSTIC build: 4 = tail cutting, 5 = every item cut in two, 6 = uncut.  Same bar as the
     product kernel (0 = 7 = attn64r), plus a spiked key (the runaway path late in the sweep).  Recorded here because it decides
-    what can ship: the cut forms do NOT reproduce the uncut form bit for bit (round 3), so a batch-size dependent cut would
-    break the tower's shard invariance."""
+    what can ship: the cut forms do NOT reproduce the uncut form bit for bit on large batches (round 3: isolated rows whose
+    reference maximum moves, tools/attn32_cut_invariance.py), so a batch-size dependent cut would break the tower's shard
+    invariance."""
     from slime_amd import ops, _lib
     E = heads * 64
     qkv = _rand((B, max(nq, nkv), 3 * E), torch.bfloat16, dev, 50)
