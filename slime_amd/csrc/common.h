@@ -35,6 +35,11 @@ struct BF16 {
     static __device__ __forceinline__ void mfma16_agpr(f32x4& acc, u32x4 a, u32x4 b) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     }
+    // the same with the accumulator pinned to the ARCH VGPR file (kernels whose whole register budget is <= 256: the epilogue
+    // then reads its results without a v_accvgpr_read per element)
+    static __device__ __forceinline__ void mfma16_vgpr(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // RNE
@@ -54,6 +59,9 @@ struct F16 {
     }
     static __device__ __forceinline__ void mfma16_agpr(f32x4& acc, u32x4 a, u32x4 b) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma16_vgpr(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};

@@ -963,7 +963,7 @@ constexpr int db_younger(int mi, int nj, bool prev_dma, bool cur_dma, bool cur_g
 // measured SLOWER than the 128 x 128 lock-step kernel there (tower over 5 crops 3.70 -> 3.95 ms with fc2 on it, 9 crops 4.84 -> 5.07;
 // profiles/r03_small_batch_latency_b.txt): a 16-MFMA k-step (270 cycles) is shorter than the latency of the weight fragments
 // requested one k-step ahead, and an under-filled chip has no second wave per SIMD to cover it.
-template <typename T, int EPI, int KTAG, int MI>
+template <typename T, int EPI, int KTAG, int MI, bool AV = false>
 __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     constexpr int NJ = 4, BM = 16 * MI, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = MI / 2;
     static_assert(MI == 8 || MI == 4, "direct-B tile heights: 128 or 64 rows");
@@ -1053,7 +1053,8 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = MI * nj + mi;
-                T::mfma16_agpr(acc[mi][nj], FB[nj], cur[mi]);
+                if constexpr (AV) T::mfma16_vgpr(acc[mi][nj], FB[nj], cur[mi]);
+                else T::mfma16_agpr(acc[mi][nj], FB[nj], cur[mi]);
                 if constexpr (R) { if (m % 4 == 1) read_frag(nxt[m / 4], m / 4, xbase_next); }
                 if constexpr (D) { if (m % MI == MI / 2 - 1 && m / MI < AP) dma(m / MI, dma_tile); }
                 if constexpr (G) { if (mi == MI - 1) gl(njc, next_kstep); }
@@ -1087,7 +1088,10 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (AV) asm volatile("" : "+v"(acc[i][j]));
+            else asm volatile("" : "+a"(acc[i][j]));
+        }
 #ifdef SLIME_DIAG
     if (g.db_abl & 2) return;
     if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; }
@@ -1673,19 +1677,19 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 
-template <typename T, int EPI, int KTAG, int MI>
+template <typename T, int EPI, int KTAG, int MI, bool AV = false>
 static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 16 * MI;
     constexpr int LDS = 2 * BM * 64 * 2 + BM * 8;                   // two A stages + the LayerNorm-fold row table
-    auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
+    auto kern = gemm_db_kernel<T, EPI, KTAG, MI, AV>;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_db");
     return SLIME_OK;
 }
-template <typename T, int EPI, int MI>
+template <typename T, int EPI, int MI, bool AV = false>
 static int launch_db(const GemmArgs& g, hipStream_t stream) {
-    return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI>(g, stream) : launch_db_k<T, EPI, 0, MI>(g, stream);
+    return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI, AV>(g, stream) : launch_db_k<T, EPI, 0, MI, AV>(g, stream);
 }
 
 template <typename T, int EPI>
@@ -1763,7 +1767,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
     if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
-    if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 12 ? 11 : 3;
+    if ((tile == 12 || tile == 13 || tile == 14) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
@@ -1777,8 +1781,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
+    if (tile == 14) return launch_db<T, EPI, 8, true>(g, stream); // accumulators in arch VGPRs
 #else
-    if (tile == 13) return launch_db<T, EPI, 8>(g, stream);
+    if (tile == 13 || tile == 14) return launch_db<T, EPI, 8>(g, stream);
 #endif
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
