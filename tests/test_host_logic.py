@@ -230,3 +230,47 @@ def test_splice_plan_matches_reference(name):
         assert np.array_equal(pos, c["out_position_ids"].numpy())
     with pytest.raises(ValueError, match="fewer image features"):
         splice_plan(c["input_ids"].numpy(), am, lb, [f.shape[0] for f in c["feats"]][:-1], c["max_length"], c["padding_side"])
+
+
+def test_gather_chunk_cost_model():
+    """slime_amd.dist.choose_chunk: one tower pass + one all-gather at every per-rank size BASELINE's configs produce (round 2's
+    fixed chunk of 3 doubled a 9-crop shard's tower time); micro-batches only where the modelled transfer exceeds a second pass."""
+    from slime_amd import dist as D
+    for n in (1, 5, 9, 17, 34, 40, 68):
+        assert abs(D.tower_ms(n) - (D.TOWER_MS[n] if n in D.TOWER_MS else D.tower_ms(n))) < 1e-9
+    assert D.tower_ms(0) == 0.0 and D.tower_ms(7) == pytest.approx((D.TOWER_MS[6] + D.TOWER_MS[8]) / 2)
+    assert D.tower_ms(60) == pytest.approx(D.TOWER_MS[40] + 0.334 * 20)
+    assert all(D.tower_ms(a) <= D.tower_ms(b) for a, b in zip(range(1, 80), range(2, 81)))          # monotone
+    assert D.gather_ms(9, 1) == 0.0 and D.gather_ms(9, 8) == pytest.approx(0.03 + 7 * 9 * 576 * 1024 * 2 / 100e6)
+    for per, world in ((40, 1), (20, 2), (10, 4), (5, 8), (34, 2), (17, 4), (9, 8), (1, 8)):
+        assert D.choose_chunk(per, world) == 0, (per, world)
+    big = D.choose_chunk(400, 8)
+    assert 0 < big < 400
+    # the choice is the argmin of the model it documents
+    one = D.tower_ms(400) + D.gather_ms(400, 8)
+    sizes = [min(big, 400 - i) for i in range(0, 400, big)]
+    assert sum(D.tower_ms(x) for x in sizes) + D.gather_ms(sizes[-1], 8) < one
+
+
+def test_position_ids_broadcast_and_token_ranges_host_logic():
+    """HF hands [1, S] / None position ids to every attention layer; ops._position_ids materialises the broadcast and
+    rejects shapes that do not broadcast.  ops.token_ranges: contiguous runs only, cached per mask OBJECT."""
+    import torch
+    from slime_amd import ops
+    B, S = 3, 7
+    want = torch.arange(S, dtype=torch.int32)[None].expand(B, S)
+    for pid in (None, torch.arange(S), torch.arange(S)[None], torch.arange(S)[None].expand(B, S)):
+        got = ops._position_ids(pid, B, S, "cpu")
+        assert got.dtype == torch.int32 and got.is_contiguous() and torch.equal(got, want)
+    for bad in (torch.arange(S)[None].expand(2, S), torch.arange(S + 1), torch.zeros(B, S, 1)):
+        with pytest.raises(ValueError, match="broadcast"):
+            ops._position_ids(bad, B, S, "cpu")
+    m = torch.tensor([[1, 1, 1, 0, 0], [0, 0, 1, 1, 1], [0, 0, 0, 0, 0]])
+    st, ln = ops.token_ranges(m)
+    assert st.tolist() == [0, 2, 0] and ln.tolist() == [3, 3, 0]
+    assert ops.token_ranges(m)[0] is st
+    m[0, 3] = 1
+    assert ops.token_ranges(m)[1].tolist() == [4, 3, 0]
+    with pytest.raises(ValueError, match="contiguous"):
+        ops.token_ranges(torch.tensor([[1, 0, 1, 1]]))
+    assert ops.token_ranges(None) == (None, None)
