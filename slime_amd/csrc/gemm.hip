@@ -445,9 +445,82 @@ gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    float* lnrow = reinterpret_cast<float*>(smem + 2 * STAGE);
+    // SCHED 2 (round 3): the same tile with a THREE-stage ring and the DMA of k-tile t+2 issued while k-tile t is multiplied.
+    // For grids that do not give every CU a workgroup (rank shards of 1-10 crops) there is no second wave per SIMD to cover a
+    // stage that has not landed, and with one tile of look-ahead (32 MFMAs per wave = 540 cycles) against an L2 / HBM latency
+    // of 500-2000 cycles the two-stage loop waits in every k-tile (fc2 at 2885 rows: 63 us for 24 GF).  The DMA is inline asm
+    // (SGPR base + per-lane offset) so that hipcc neither drains it at the barrier nor guards the fragment reads with vmcnt(0);
+    // the barrier is the raw instruction behind a COUNTED wait (the next tile's 8 pieces stay in flight).
+    constexpr int NSTAGE = SCHED == 2 ? 3 : 2;
+    float* lnrow = reinterpret_cast<float*>(smem + NSTAGE * STAGE);
     stage_ln_rows<BM, NW * 64>(g, m0, lnrow);
     const int nk = g.K / BK;
+    if constexpr (SCHED == 2) {
+        static_assert(A_INSTR + B_INSTR == 8, "counted wait below: 8 pieces per wave and stage");
+        unsigned soff[A_INSTR + B_INSTR];
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int r = (i * NW + wave) * 8 + lrow;
+            soff[i] = (unsigned)min(r, g.M - 1 - m0) * (unsigned)g.lda * 2u + lchunk * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int rho = (i * NW + wave) * 8 + lrow, nl = rho & 15;
+            const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
+            soff[A_INSTR + i] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+        }
+        const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
+        const char* b_gbase = g.B + (size_t)n0 * g.K * 2;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem));
+        auto stage3 = [&](int tile) {
+            const unsigned base = lds0 + (tile % 3) * STAGE;
+            const char* ga = uniform_ptr(a_gbase + (size_t)tile * (BK * 2));
+            const char* gb = uniform_ptr(b_gbase + (size_t)tile * (BK * 2));
+#pragma unroll
+            for (int i = 0; i < A_INSTR; ++i) lds_dma16(soff[i], ga, base + (i * NW + wave) * 1024);
+#pragma unroll
+            for (int i = 0; i < B_INSTR; ++i) lds_dma16(soff[A_INSTR + i], gb, base + A_BYTES + (i * NW + wave) * 1024);
+        };
+        stage3(0);
+        if (nk > 1) stage3(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            // k-tile kt has landed (its pieces are older than the 8 of k-tile kt+1); every wave has finished reading k-tile kt-1
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) stage3(kt + 2);                  // into the stage k-tile kt-1 was read from
+            const char* sb = smem + (kt % 3) * STAGE;
+            u32x4 bf0[NI], af0[MI], bf1[NI], af1[MI];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf0[j] = *reinterpret_cast<const u32x4*>(sb + b_off[0] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af0[i] = *reinterpret_cast<const u32x4*>(sb + a_off[0] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bf1[j] = *reinterpret_cast<const u32x4*>(sb + b_off[1] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af1[i] = *reinterpret_cast<const u32x4*>(sb + a_off[1] + i * 2048);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = T::mfma16(bf0[j], af0[i], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = T::mfma16(bf1[j], af1[i], acc[i][j]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+            for (int r = 0; r < MI + NI; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
+            // the fragment reads of this k-tile must have RETURNED before the wave may enter the next barrier (the DMA issued
+            // behind it overwrites this stage two tiles later: the barrier after next -- but its reads are consumed by the MFMAs
+            // above, so they have)
+        }
+    } else {
     stage(0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -495,6 +568,7 @@ gemm_kernel(GemmArgs g) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
         }
+    }
     }
 
     // ---- epilogue: lane holds, per (mi, tile pair), 8 consecutive columns of one row ------------
@@ -1700,7 +1774,7 @@ static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int SCHED>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
     constexpr int STAGE = (BM + BN) * 64 * 2;
-    constexpr int LDS = 2 * STAGE + BM * 8;                         // + the LayerNorm-fold row table
+    constexpr int LDS = (SCHED == 2 ? 3 : 2) * STAGE + BM * 8;      // + the LayerNorm-fold row table
     auto kern = gemm_kernel<T, BM, BN, WAVES_M, WAVES_N, EPI, SCHED>;
     SLIME_SET_LDS_ONCE(kern, LDS, "gemm");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
@@ -1713,7 +1787,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // throughput kernels; 128x128 (4 waves, 64 KiB LDS, 2 WG/CU) covers narrow N (tiny geometries) and small M.  Partial last
 // rounds of workgroups are filled by running two half batches on two streams (see HipCLIPVisionModel.encode), not by
 // shrinking the tile.  Tile ids: 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 =
-// 192x256 / 256x256 four-wave stream kernel, 12 = 128x256 direct-B kernel (needs Bf); diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
+// 192x256 / 256x256 four-wave stream kernel, 12 = 128x256 direct-B kernel (needs Bf), 15 = 128x128 with a three-stage ring; diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
 static int auto_tile(const GemmArgs& g) {
     int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
     if (tile == 4) {
@@ -1739,6 +1813,11 @@ static int auto_tile(const GemmArgs& g) {
         // (2885 rows: fc1 669 -> 857, qkv 564 -> 649 TF/s); the two-stream tower is 2.5-3 % faster with qkv / out_proj / fc1 on it.
         if (tile != 3 && g.Bf && (n256 >= cus || g.K <= 2048)) tile = 12;
     }
+    // ... and 128 x 128 grids of at most one workgroup per CU (rank shards of 1-5 crops, single images, small adapter batches) run the
+    // three-stage form of that kernel: nothing else on the CU covers a k-tile that has not landed, so the DMA runs two tiles ahead
+    // (tower over 1 / 3 / 5 crops 3.12 -> 2.40 / 3.25 -> 2.75 / 3.68 -> 3.18 ms; beyond one workgroup per CU the two-stage form's second
+    // resident workgroup is worth more: 9 crops 4.78 vs 5.10 -- tools/rank_shapes.py, profiles/r03_small_batch_latency_c.txt)
+    if (tile == 3 && (long)((g.M + 127) / 128) * (g.N / 128) <= num_cus()) tile = 15;
     return tile;
 }
 
@@ -1766,7 +1845,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
-    if ((tile == 1 || tile >= 4) && g.N % 256 != 0) tile = 3;
+    if ((tile == 1 || (tile >= 4 && tile != 15)) && g.N % 256 != 0) tile = 3;
     if ((tile == 12 || tile == 13 || tile == 14) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
@@ -1778,6 +1857,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
     if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
 #endif
+    if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
@@ -1818,7 +1898,7 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
     else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
-    else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, 1>", t, epilogue);
+    else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, %d>", t, epilogue, tile == 15 ? 2 : 1);
     return SLIME_OK;
 }
 

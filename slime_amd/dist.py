@@ -33,11 +33,12 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
     return list(range(lo, hi))
 
 
-# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/rank_shapes.py, profiles/r03_small_batch_latency.json):
-# a pass costs ~3.1 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us kernels) and ~0.33 ms per crop
-# beyond ~16 crops, where the GEMM grids fill the chip.
-TOWER_MS = {1: 3.14, 2: 3.16, 3: 3.25, 4: 3.48, 5: 3.71, 6: 3.86, 8: 4.59, 9: 4.96, 10: 5.32, 12: 5.73, 14: 6.95, 16: 7.24, 17: 7.55,
-            20: 8.52, 24: 10.11, 34: 13.42, 40: 15.22}
+# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/rank_shapes.py, profiles/r03_small_batch_latency_c.json):
+# a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us kernels) and ~0.33 ms per crop
+# beyond ~16 crops, where the GEMM grids fill the chip.  (The step between 6 and 8 crops is the out_proj / fc2 grid crossing one
+# workgroup per CU: above it the 128 x 128 kernel runs its two-stage, two-per-CU form.)
+TOWER_MS = {1: 2.40, 2: 2.54, 3: 2.74, 4: 2.93, 5: 3.17, 6: 3.30, 8: 4.47, 9: 4.81, 10: 5.16, 12: 5.63, 14: 6.65, 16: 7.20, 17: 7.49,
+            20: 8.43, 24: 9.89, 34: 13.22, 40: 15.11}
 
 
 def tower_ms(n: int) -> float:
@@ -67,7 +68,7 @@ def choose_chunk(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2
     micro-batch's transfer under the remaining tower work but pays the tower's per-pass floor once per extra micro-batch:
     it is chosen only where the modelled saving exceeds that cost.  With the measured curve that is never the case at the
     per-rank sizes of BASELINE configs 2 / 3 / 5 (5 ... 34 crops: a second pass costs 1.8-3 ms, the whole transfer <= 0.8 ms
-    -- round 2's fixed chunk of 3 turned 9 crops from 4.96 into 9.74 ms); it starts to pay at ~100 crops per rank on 8 GPUs."""
+    -- round 2's fixed chunk of 3 turned 9 crops from 4.8 into 8.2-9.7 ms); it starts to pay at ~100 crops per rank on 8 GPUs."""
     if world <= 1 or per_rank < 2:
         return 0
     best, best_t = 0, tower_ms(per_rank) + gather_ms(per_rank, world, bytes_per_crop, link_gb_s)

@@ -36,7 +36,7 @@ def _rand(shape, dtype, dev, seed, scale=1.0):
 
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (3, 1), (3, 0), (0, 1), (4, 1), (5, 1), (7, 1), (9, 1), (10, 1), (11, 1)])
+@pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (3, 1), (3, 0), (0, 1), (4, 1), (5, 1), (7, 1), (9, 1), (10, 1), (11, 1), (15, 1)])
 @pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128)])
 def test_gemm_epilogues(dev, dtype, tile, sched, M, N, K):
     """Every tile / kernel variant (forced through the DIAGNOSTIC build's hook) x every epilogue vs fp32 torch."""

@@ -57,12 +57,13 @@ for n in (5, 9, 10, 17, 20):
         rec[label] = {"us": round(avg * 1e3, 1), "min_us": round(min(ms) * 1e3, 1), "tflops": round(fl / avg / 1e9), "kernel": names[kid]}
     out["kernels"][n] = rec
     print(f"{n} crops: " + "  ".join(f"{k} {v['us']} us ({v['tflops']} TF/s)" for k, v in rec.items()), file=sys.stderr, flush=True)
-# sub-round grids: LDS-staged auto choice (128x128 / ping-pong) vs the direct-B kernel forced per shape
-out["forced_direct_b_ms"] = {}
+# small grids: the shipped dispatch (128x128 three-stage ring where the grid has at most one workgroup per CU) against the two-stage
+# form of the same kernel forced per shape, and the direct-B kernel forced onto the small grids
+out["forced_tiles_ms"] = {}
 SH4 = [(1024, 4096), (1024, 1024), (3072, 1024), (4096, 1024)]
-RULES = {"auto": {}, "fc2->db64": {SH4[0]: 13}, "fc2,out->db64": {SH4[0]: 13, SH4[1]: 13}, "all->db64": {k: 13 for k in SH4},
-         "fc2,out->db64 qkv,fc1->db128": {SH4[0]: 13, SH4[1]: 13, SH4[2]: 12, SH4[3]: 12}, "all->db128": {k: 12 for k in SH4}}
-for n in (1, 2, 3, 5, 9, 10, 12, 17, 20):
+RULES = {"auto": {}, "fc2,out two-stage": {SH4[0]: 3, SH4[1]: 3}, "all four two-stage": {k: 3 for k in SH4},
+         "all four three-stage": {k: 15 for k in SH4}, "all four direct-B 128": {k: 12 for k in SH4}}
+for n in (1, 2, 3, 4, 5, 6, 8, 9, 10):
     x = px[:n].contiguous()
     row = {}
     for name, rules in RULES.items():
@@ -70,6 +71,6 @@ for n in (1, 2, 3, 5, 9, 10, 12, 17, 20):
         for (N, K), tile in rules.items(): lib.slime_gemm_set_shape_tile(N, K, tile)
         row[name] = round(t_ms(lambda: vm.encode(x)), 3)
     lib.slime_gemm_set_shape_tile(0, 0, 0)
-    out["forced_direct_b_ms"][n] = row
+    out["forced_tiles_ms"][n] = row
     print(f"{n:3d} crops: " + "  ".join(f"{k} {v:.3f}" for k, v in row.items()), file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))
