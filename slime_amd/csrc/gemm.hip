@@ -1846,7 +1846,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
     if ((tile == 1 || (tile >= 4 && tile != 15)) && g.N % 256 != 0) tile = 3;
-    if ((tile == 12 || tile == 13 || tile == 14) && !g.Bf) tile = tile == 13 ? 3 : 11;
+    if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
@@ -1861,9 +1861,10 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
-    if (tile == 14) return launch_db<T, EPI, 8, true>(g, stream); // accumulators in arch VGPRs
+    // (tile 14 = launch_db<T, EPI, 8, true>: accumulators in arch VGPRs -- measured -0.4 %, 28-49 spilled registers in the T-output
+    // epilogues; no longer instantiated)
 #else
-    if (tile == 13 || tile == 14) return launch_db<T, EPI, 8>(g, stream);
+    if (tile == 13) return launch_db<T, EPI, 8>(g, stream);
 #endif
     if (tile == 4) return launch_pp<T, EPI>(g, stream);
     if (tile == 10) return launch_w4<T, EPI, 6>(g, stream);
