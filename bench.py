@@ -376,7 +376,7 @@ def main():
         path_tflops = step_gf * (1 if strong else world) / (elapsed / args.steps) / 1e3
         halves = 2 if tower.vision_tower.two_streams else 1
         per_rank = -(-n_step // world) if strong else n_step
-        n_half = per_rank // halves if per_rank >= 16 else per_rank
+        n_half = (per_rank + 1) // halves if per_rank >= 8 else per_rank          # encode() splits from 8 crops on
         dom, per = kernel_roofline(tower.vision_tower, pixels[:n_half].contiguous())
         roof_kernel = per[dom]
         if prefill:

@@ -33,12 +33,12 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
     return list(range(lo, hi))
 
 
-# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/rank_shapes.py, profiles/r03_small_batch_latency_c.json):
-# a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us kernels) and ~0.33 ms per crop
-# beyond ~16 crops, where the GEMM grids fill the chip.  (The step between 6 and 8 crops is the out_proj / fc2 grid crossing one
-# workgroup per CU: above it the 128 x 128 kernel runs its two-stage, two-per-CU form.)
-TOWER_MS = {1: 2.40, 2: 2.54, 3: 2.74, 4: 2.93, 5: 3.17, 6: 3.30, 8: 4.47, 9: 4.81, 10: 5.16, 12: 5.63, 14: 6.65, 16: 7.20, 17: 7.49,
-            20: 8.43, 24: 9.89, 34: 13.22, 40: 15.11}
+# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/stream_split_sweep.py, tools/rank_shapes.py;
+# profiles/r03_stream_split_sweep.txt): a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us
+# kernels) and ~0.33 ms per crop beyond ~16 crops, where the GEMM grids fill the chip.  From 8 crops on encode() runs two half batches
+# on two streams (the step between 7 and 8 crops is the out_proj / fc2 grid crossing one workgroup per CU).
+TOWER_MS = {1: 2.40, 2: 2.55, 3: 2.74, 4: 2.94, 5: 3.16, 6: 3.29, 7: 3.49, 8: 4.36, 9: 4.43, 10: 4.61, 12: 5.28, 14: 5.91, 16: 7.22,
+            17: 7.55, 20: 8.40, 24: 9.87, 28: 10.52, 34: 13.33, 40: 15.11}
 
 
 def tower_ms(n: int) -> float:

@@ -83,6 +83,7 @@ class HipCLIPVisionModel(nn.Module):
         self.vision_model = _VisionTransformer(config)
         self.compute_dtype = compute_dtype     # MFMA operand type used when the parameters are fp32
         self.two_streams = True
+        self.force_streams = 0                # tools/stream_split_sweep.py: 1 / 2 = override the split policy below
         self._packed: Dict = {}
         self._streams: Optional[List[torch.cuda.Stream]] = None
         self.requires_grad_(False)
@@ -131,7 +132,14 @@ class HipCLIPVisionModel(nn.Module):
         """[N,3,S,S] -> hidden_states[select_layer] as [N, P(+1), D] (one batched launch sequence)."""
         out_dtype = out_dtype or pixel_values.dtype
         n = pixel_values.shape[0]
-        if not (self.two_streams and n >= 16):             # measured break-even: 14-16 crops (tools/small_streams.py)
+        # two half batches on two streams from 8 crops on: round 3's sweep (tools/stream_split_sweep.py, profiles/r03_stream_split_sweep.txt)
+        # has the split ahead or equal at every count >= 8 (9 crops 4.79 -> 4.43 ms, 14: 6.65 -> 5.91, 40: 16.5 -> 15.1) and behind
+        # below (7 crops 3.49 vs 4.01: two passes of the 2.4 ms floor); rounds 1-2 measured 14-16 as the break-even with the old
+        # small-grid kernels
+        split = self.two_streams and n >= 8
+        if self.force_streams:
+            split = self.force_streams == 2 and n >= 2
+        if not split:
             return ops.tower_forward(self.packed(select_layer), pixel_values, out_dtype, keep_cls)
         # two independent half batches on two streams: fills each kernel's last partial round
         if self._streams is None:

@@ -54,7 +54,7 @@ def test_vision_tower_module(dev, dtype):
     assert tower.dtype == dtype and tower.device.type == "cuda" and tower.hidden_size == 128
     px = W.synthetic_pixels(17, seed=5)
     ref = O.tower_forward(tsd, W.TINY, px)
-    out = tower(px.to(dev).to(dtype))                          # >= 16 crops: two-stream path (9 + 8)
+    out = tower(px.to(dev).to(dtype))                          # >= 8 crops: two-stream path (9 + 8)
     assert out.dtype == dtype and out.shape == (17, 576, 128)
     assert rel_l2(out.float().cpu(), ref) < TOL[dtype] * 1.5
     tower.vision_tower.two_streams = False
