@@ -238,7 +238,7 @@ def test_gather_chunk_cost_model():
     from slime_amd import dist as D
     for n in (1, 5, 9, 17, 34, 40, 68):
         assert abs(D.tower_ms(n) - (D.TOWER_MS[n] if n in D.TOWER_MS else D.tower_ms(n))) < 1e-9
-    assert D.tower_ms(0) == 0.0 and D.tower_ms(7) == pytest.approx((D.TOWER_MS[6] + D.TOWER_MS[8]) / 2)
+    assert D.tower_ms(0) == 0.0 and D.tower_ms(11) == pytest.approx((D.TOWER_MS[10] + D.TOWER_MS[12]) / 2)
     assert D.tower_ms(60) == pytest.approx(D.TOWER_MS[40] + 0.334 * 20)
     assert all(D.tower_ms(a) <= D.tower_ms(b) for a, b in zip(range(1, 80), range(2, 81)))          # monotone
     assert D.gather_ms(9, 1) == 0.0 and D.gather_ms(9, 8) == pytest.approx(0.03 + 7 * 9 * 576 * 1024 * 2 / 100e6)
