@@ -999,9 +999,12 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 // qkv 1055 -> 1257 TF/s (K = 1024); at K = 4096 the two-workgroup form trails (fc2 1278 -> 1182, N = K = 4096 1524 -> 1462).
 //
 // Stream of one wave, per k-step (32 MFMAs, weight fragment nj outer / activation fragment mi inner):
-//   * weight fragment nj lives in 4 VGPRs for its 8 MFMAs and is re-requested for the NEXT k-step right behind the last of
-//     them (rolling single buffer; the request is in flight for 24 MFMAs ~ 800 cycles); the loads are inline asm with "+v"
-//     destinations (hipcc would otherwise drain every LDS-DMA in front of their first use) and hand-counted vmcnt waits;
+//   * weight fragment nj of a tile's k-step ks lives in 4 VGPRs (set FB[ks]) for its 8 MFMAs and is re-requested for the same
+//     k-step of the NEXT tile right behind the last of them (two rolling sets: a request is in flight for two k-steps = 64 MFMAs
+//     ~ 1100 cycles.  The first version requested one k-step ahead: equal on full grids, but a workgroup that has its CU to
+//     itself -- sub-round grids -- then waits for every fragment set: fc2 at 5193-6924 rows +8-10 %, tower over 17 / 24 crops
+//     7.32 -> 6.87 / 9.92 -> 9.29 ms, profiles/r03_db_deep_*.txt); the loads are inline asm with "+v" destinations (hipcc would
+//     otherwise drain every LDS-DMA in front of their first use) and hand-counted vmcnt waits;
 //   * activation fragments are double buffered from LDS (ordinary loads, the compiler counts lgkmcnt), one read per 4 MFMAs;
 //   * k-step 1 of a tile also issues the wave's 4 LDS-DMA pieces of the tile after next; ONE barrier per k-tile.
 // VMEM order inside a k-step: D_j behind MFMA 8 j + 3, G_nj behind MFMA 8 nj + 7.
@@ -1020,14 +1023,17 @@ template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
-// VMEM requests younger than weight request G_nj of the PREVIOUS k-step at the moment MFMA group nj of the current one starts
-// (mi = 16-row MFMA tiles per wave: DMA piece j of the wave's mi/2 follows MFMA mi*j + mi/2 - 1, request G_nj follows MFMA mi*nj + mi - 1)
-constexpr int db_younger(int mi, int nj, bool prev_dma, bool cur_dma, bool cur_gl) {
-    int c = (3 - nj) + (cur_gl ? nj : 0);
-    for (int j = 0; j < mi / 2; ++j) {
-        const int pos = mi * j + mi / 2 - 1;
-        if (prev_dma && pos > mi * nj + mi - 1) ++c;
-        if (cur_dma && pos < mi * nj) ++c;
+// VMEM requests younger than weight request G_nj -- issued TWO k-steps before its use -- at the moment MFMA group nj of the current
+// k-step starts (mi = 16-row MFMA tiles per wave: DMA piece j of the wave's mi/2 follows MFMA mi*j + mi/2 - 1, request G_nj follows
+// MFMA mi*nj + mi - 1).  ks: k-step of the tile; more: a next tile exists (both k-steps of this tile request fragments, the previous
+// tile refilled a stage); refill: k-step 1 of this tile carries the DMA pieces.
+constexpr int db_younger(int mi, int nj, int ks, bool more, bool refill) {
+    int c = 3 - nj;                                                       // rest of k-step s-2's requests
+    if (ks == 0) c += 4 + (more ? mi / 2 : 0) + (more ? nj : 0);          // k-step s-1 = k-step 1 of the previous tile: 4 requests (+ its mi/2 pieces)
+    else {
+        for (int j = 0; j < mi / 2; ++j) if (more && mi * j + mi / 2 - 1 > mi * nj + mi - 1) ++c;      // pieces behind G_nj in k-step s-2
+        c += (more ? 4 : 0) + (more ? nj : 0);                            // k-step s-1 = k-step 0 of this tile; this k-step's requests so far
+        for (int j = 0; j < mi / 2; ++j) if (refill && mi * j + mi / 2 - 1 < mi * nj) ++c;             // this k-step's pieces so far
     }
     return c;
 }
@@ -1037,7 +1043,7 @@ constexpr int db_younger(int mi, int nj, bool prev_dma, bool cur_dma, bool cur_g
 // measured SLOWER than the 128 x 128 lock-step kernel there (tower over 5 crops 3.70 -> 3.95 ms with fc2 on it, 9 crops 4.84 -> 5.07;
 // profiles/r03_small_batch_latency_b.txt): a 16-MFMA k-step (270 cycles) is shorter than the latency of the weight fragments
 // requested one k-step ahead, and an under-filled chip has no second wave per SIMD to cover it.
-template <typename T, int EPI, int KTAG, int MI, bool AV = false>
+template <typename T, int EPI, int KTAG, int MI>
 __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     constexpr int NJ = 4, BM = 16 * MI, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = MI / 2;
     static_assert(MI == 8 || MI == 4, "direct-B tile heights: 128 or 64 rows");
@@ -1078,12 +1084,14 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     // this wave's weight stream: 4 KiB per k-step, contiguous over k-steps
     const char* bw = uniform_ptr(g.Bf + ((size_t)(n0 / 64 + wave) * (size_t)(g.K / 32)) * 4096);
     const unsigned boff = lane * 16;
-    u32x4 FB[NJ];
+    u32x4 FB[2][NJ];                                                  // FB[0]: fragments of a tile's k-step 0, FB[1]: of its k-step 1
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) FB[j] = u32x4{0u, 0u, 0u, 0u};
-    auto gl = [&](auto jc, int kstep) {
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) FB[ks][j] = u32x4{0u, 0u, 0u, 0u};
+    auto gl = [&](auto ksc, auto jc, int kstep) {
         constexpr int j = decltype(jc)::value;
-        gload16_frag<j * 1024>(FB[j], boff, uniform_ptr(bw + (size_t)kstep * 4096));
+        gload16_frag<j * 1024>(FB[decltype(ksc)::value][j], boff, uniform_ptr(bw + (size_t)kstep * 4096));
     };
 
     int xb[2];
@@ -1107,7 +1115,8 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < AP; ++j) dma(j, 1);
     }
-    static_for<0, NJ>([&](auto jc) { gl(jc, 0); });
+    static_for<0, NJ>([&](auto jc) { gl(std::integral_constant<int, 0>{}, jc, 0); });
+    static_for<0, NJ>([&](auto jc) { gl(std::integral_constant<int, 1>{}, jc, 1); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_barrier" ::: "memory");
@@ -1117,55 +1126,53 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     auto read_frag = [&](u32x4& dstF, int i, int xbase) { dstF = *reinterpret_cast<const u32x4*>(smem + xbase + i * 2048); };
     using Yes = std::integral_constant<bool, true>;
     using No = std::integral_constant<bool, false>;
-    // One k-step.  prev_dma / dmas: the previous / this k-step carries the 4 refill pieces; gls: request the weight fragments of
-    // `next_kstep`; reads: fetch the activation fragments of the next k-step from xbase_next.
-    auto kstep = [&](u32x4 (&cur)[MI], u32x4 (&nxt)[MI], auto prev_dma, auto dmas, int dma_tile, auto gls, int next_kstep, auto reads, int xbase_next) {
-        constexpr bool PD = decltype(prev_dma)::value, D = decltype(dmas)::value, G = decltype(gls)::value, R = decltype(reads)::value;
+    // One k-step (KS = 0 / 1 of its tile) on the fragment set FB[KS]; every fragment is re-requested for the same k-step of the NEXT
+    // tile right behind its last MFMA (rolling buffer, two k-steps = 64 MFMAs ~ 1100 cycles of flight).  more: a next tile exists;
+    // dmas: this k-step issues the wave's DMA pieces of tile dma_tile; reads: fetch the activation fragments of the next k-step.
+    auto kstep = [&](u32x4 (&cur)[MI], u32x4 (&nxt)[MI], auto ksc, auto more, auto dmas, int dma_tile, int next_kstep, auto reads, int xbase_next) {
+        constexpr int KS = decltype(ksc)::value;
+        constexpr bool MORE = decltype(more)::value, D = decltype(dmas)::value, R = decltype(reads)::value;
         static_for<0, NJ>([&](auto njc) {
             constexpr int nj = decltype(njc)::value;
-            vm_wait_frag<db_younger(MI, nj, PD, D, G)>(FB[nj]);
+            vm_wait_frag<db_younger(MI, nj, KS, MORE, D)>(FB[KS][nj]);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = MI * nj + mi;
-                if constexpr (AV) T::mfma16_vgpr(acc[mi][nj], FB[nj], cur[mi]);
-                else T::mfma16_agpr(acc[mi][nj], FB[nj], cur[mi]);
+                T::mfma16_agpr(acc[mi][nj], FB[KS][nj], cur[mi]);
                 if constexpr (R) { if (m % 4 == 1) read_frag(nxt[m / 4], m / 4, xbase_next); }
                 if constexpr (D) { if (m % MI == MI / 2 - 1 && m / MI < AP) dma(m / MI, dma_tile); }
-                if constexpr (G) { if (mi == MI - 1) gl(njc, next_kstep); }
+                if constexpr (MORE) { if (mi == MI - 1) gl(ksc, njc, next_kstep); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         });
     };
-    auto tile_body = [&](int t, auto prev_dma, auto more, auto refill) {
+    auto tile_body = [&](int t, auto more, auto refill) {
         const int so = (t & 1) * A_BYTES, sn = ((t + 1) & 1) * A_BYTES;
-        kstep(FA[0], FA[1], prev_dma, No{}, 0, Yes{}, 2 * t + 1, Yes{}, xb[1] + so);
+        kstep(FA[0], FA[1], std::integral_constant<int, 0>{}, more, No{}, 0, 2 * t + 2, Yes{}, xb[1] + so);
         if constexpr (decltype(more)::value) {
-            // tile t+1 has landed (only this k-step's 4 weight requests are younger than its pieces); every read of tile t has returned
+            // tile t+1 has landed (younger than its last piece: one request of that k-step and this k-step's four); every read of
+            // tile t has returned
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
-        kstep(FA[1], FA[0], No{}, refill, t + 2, more, 2 * t + 2, more, xb[0] + sn);
+        kstep(FA[1], FA[0], std::integral_constant<int, 1>{}, more, refill, t + 2, 2 * t + 3, more, xb[0] + sn);
     };
-
 #pragma unroll
     for (int i = 0; i < MI; ++i) read_frag(FA[0][i], i, xb[0]);
 
     int t = 0;
-    for (; t + 2 < nk; ++t) tile_body(t, Yes{}, Yes{}, Yes{});
-    if (t + 1 < nk) { tile_body(t, Yes{}, Yes{}, No{}); ++t; }
-    tile_body(t, No{}, No{}, No{});
+    for (; t + 2 < nk; ++t) tile_body(t, Yes{}, Yes{});
+    if (t + 1 < nk) { tile_body(t, Yes{}, No{}); ++t; }
+    tile_body(t, No{}, No{});
 
     // hand-written MFMAs: pad the matrix pipe's write-back latency and tie every accumulator behind the padding (see gemm_w4_kernel)
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if constexpr (AV) asm volatile("" : "+v"(acc[i][j]));
-            else asm volatile("" : "+a"(acc[i][j]));
-        }
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
 #ifdef SLIME_DIAG
     if (g.db_abl & 2) return;
     if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; }
@@ -1751,19 +1758,19 @@ static int launch_w4(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_w4_k<T, EPI, 1, MI>(g, stream) : launch_w4_k<T, EPI, 0, MI>(g, stream);
 }
 
-template <typename T, int EPI, int KTAG, int MI, bool AV = false>
+template <typename T, int EPI, int KTAG, int MI>
 static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 16 * MI;
     constexpr int LDS = 2 * BM * 64 * 2 + BM * 8;                   // two A stages + the LayerNorm-fold row table
-    auto kern = gemm_db_kernel<T, EPI, KTAG, MI, AV>;
+    auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
     hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_db");
     return SLIME_OK;
 }
-template <typename T, int EPI, int MI, bool AV = false>
+template <typename T, int EPI, int MI>
 static int launch_db(const GemmArgs& g, hipStream_t stream) {
-    return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI, AV>(g, stream) : launch_db_k<T, EPI, 0, MI, AV>(g, stream);
+    return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI>(g, stream) : launch_db_k<T, EPI, 0, MI>(g, stream);
 }
 
 template <typename T, int EPI>
@@ -1813,6 +1820,10 @@ static int auto_tile(const GemmArgs& g) {
         // (2885 rows: fc1 669 -> 857, qkv 564 -> 649 TF/s); the two-stream tower is 2.5-3 % faster with qkv / out_proj / fc1 on it.
         if (tile != 3 && g.Bf && (n256 >= cus || g.K <= 2048)) tile = 12;
     }
+    // ... and K > 2048 grids (fc2) in the band where the rule above falls back to the two-stage 128 x 128 kernel although its grid
+    // exceeds one workgroup per CU (half batches of 8-12 crops): the direct-B kernel's two-k-step fragment flight covers an under-
+    // filled chip better (tower over 17 / 20 / 24 crops 7.32 -> 6.87 / 8.30 -> 7.99 / 9.92 -> 9.29 ms; out_proj, K = 1024, does not gain)
+    if (tile == 3 && g.Bf && g.K > 2048 && g.N % 256 == 0 && (long)((g.M + 127) / 128) * (g.N / 128) > num_cus()) tile = 12;
     // ... and 128 x 128 grids of at most one workgroup per CU (rank shards of 1-5 crops, single images, small adapter batches) run the
     // three-stage form of that kernel: nothing else on the CU covers a k-tile that has not landed, so the DMA runs two tiles ahead
     // (tower over 1 / 3 / 5 crops 3.12 -> 2.40 / 3.25 -> 2.75 / 3.68 -> 3.18 ms; beyond one workgroup per CU the two-stage form's second
@@ -1861,8 +1872,6 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
-    // (tile 14 = launch_db<T, EPI, 8, true>: accumulators in arch VGPRs -- measured -0.4 %, 28-49 spilled registers in the T-output
-    // epilogues; no longer instantiated)
 #else
     if (tile == 13) return launch_db<T, EPI, 8>(g, stream);
 #endif

@@ -37,8 +37,8 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
 # profiles/r03_stream_split_sweep.txt): a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us
 # kernels) and ~0.33 ms per crop beyond ~16 crops, where the GEMM grids fill the chip.  From 8 crops on encode() runs two half batches
 # on two streams (the step between 7 and 8 crops is the out_proj / fc2 grid crossing one workgroup per CU).
-TOWER_MS = {1: 2.40, 2: 2.55, 3: 2.74, 4: 2.94, 5: 3.16, 6: 3.29, 7: 3.49, 8: 4.36, 9: 4.43, 10: 4.61, 12: 5.28, 14: 5.91, 16: 7.22,
-            17: 7.55, 20: 8.40, 24: 9.87, 28: 10.52, 34: 13.33, 40: 15.11}
+TOWER_MS = {1: 2.40, 2: 2.55, 3: 2.75, 4: 2.93, 5: 3.15, 6: 3.31, 7: 3.56, 8: 4.38, 9: 4.45, 10: 4.74, 12: 5.39, 14: 5.94, 16: 6.77,
+            17: 7.05, 20: 8.11, 24: 9.32, 28: 10.54, 34: 13.21, 40: 15.22}
 
 
 def tower_ms(n: int) -> float:

@@ -125,9 +125,11 @@ def _check_direct_b(dev, dtype, M, N, K, forced):
     wf = ops.pack_b_frag(w)
     assert wf is not None
     if not forced:
-        # the dispatch rule (gemm.hip auto_tile): fragment-order B -> direct-B kernel, except sub-round grids with K > 2048
-        sub_round_long_k = K > 2048 and ((M + 255) // 256) * (N // 256) < 256
-        assert ("gemm_db_kernel" in ops.gemm_kernel_name(M, N, K, dtype, _lib.EPI_BIAS_T, True)) == (not sub_round_long_k)
+        # the dispatch rule (gemm.hip auto_tile): fragment-order B -> direct-B kernel, except K > 2048 grids between half a round and
+        # one round of 256-row tiles (fc2 at a 20-crop half batch: ping-pong kernel)
+        n256 = ((M + 255) // 256) * (N // 256)
+        pp_band = K > 2048 and 128 <= n256 < 256
+        assert ("gemm_db_kernel" in ops.gemm_kernel_name(M, N, K, dtype, _lib.EPI_BIAS_T, True)) == (not pp_band)
         assert "gemm_db_kernel" not in ops.gemm_kernel_name(M, N, K, dtype, _lib.EPI_BIAS_T, False)
     ref = a.float() @ w.float().t() + bias
     for epi, fn, tol in ((_lib.EPI_BIAS_F32, lambda r: r, TOL_F32), (_lib.EPI_BIAS_T, lambda r: r, TOL_T[dtype]),
@@ -179,7 +181,7 @@ def _check_direct_b(dev, dtype, M, N, K, forced):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(11540, 3072, 1024), (11540, 4096, 1024), (11540, 1024, 4096), (11540, 1024, 1024), (13824, 4096, 4096),
-                                   (5193, 3072, 1024), (23080, 1024, 1024)])
+                                   (5193, 3072, 1024), (23080, 1024, 1024), (5770, 1024, 4096)])
 def test_gemm_direct_b_production_shapes(dev, dtype, M, N, K):
     """The tower's launch shapes through the PRODUCT library's auto dispatch with B_frag set (20-crop half batch, the stacked
     adapter MLP, a 9-crop rank shard, a 40-crop batch): gemm_db_kernel, ragged last row tile (11540 = 90 x 128 + 20)."""
