@@ -19,14 +19,19 @@
 //     32 CUs of an XCD work on a GROUP_M x 8 patch of tiles that share A/B panels through their L2.
 //
 // Kernels (launch_epi picks one; slime_gemm_force_tile overrides for A/B tests):
+//   gemm_db_kernel   DIRECT-B kernel (round 3), 128x256: the static operand in MFMA-fragment order (slime_gemm_pack_b) loaded
+//                    straight into VGPRs, only A through LDS, two workgroups per CU -- wherever the caller supplies B_frag and
+//                    the grid is not small (the tower's q/k/v, out_proj, fc1, patch embed; the adapter's and Llama's projections)
 //   gemm_w4_kernel   four-wave STREAM kernel, 256x256 / 192x256: reads and DMA interleaved into one MFMA
-//                    stream per SIMD, accumulators in AGPRs, one barrier per k-tile -- grids of >= 256 tiles
+//                    stream per SIMD, accumulators in AGPRs, one barrier per k-tile -- grids of >= 256 tiles without B_frag
 //   gemm_pp_kernel   eight-wave PING-PONG kernel, 256x256 / 192x256 -- sub-round grids (they co-run best
 //                    with the other tower stream's kernels)
-//   gemm_kernel      lock-step kernel, 128x128 (narrow N, tiny M) and 256x256
+//   gemm_kernel      lock-step kernel, 128x128 (narrow N, small M; two-stage, or a three-stage ring for grids of at most one
+//                    workgroup per CU) and 256x256
 //   gemm_ppp_kernel, gemm_pp32b_kernel   persistent / 32x32x16-MFMA ping-pong variants kept as measured alternatives
 //
-// Epilogues: bias -> T; bias+quick-GELU -> T; bias+erf-GELU -> T; bias -> fp32; fp32 += (residual).
+// Epilogues: bias -> T; bias+quick-GELU -> T; bias+erf-GELU -> T; bias -> fp32; fp32 += (residual) [+ T copy and LayerNorm partial
+// sums]; T(acc + bias + T residual).
 #include "common.h"
 #include <type_traits>
 
@@ -991,7 +996,7 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 // kernels permute them while staging -- and a wave fetches its fragments with plain global_load_dwordx4 (1 KiB, fully
 // coalesced, L2 resident).  Doing only that at the stream kernel's geometry (256 x 256, one wave per SIMD) is worth 0-3 %:
 // 8 LDS-DMA + 16 ds_read_b128 are traded for 16 register loads that cost the in-order stream about as much.  What the layout
-// buys is the OTHER geometry: with B out of LDS a workgroup needs 32 KiB (A only) and a wave 128 accumulators + 80 fragment
+// buys is the OTHER geometry: with B out of LDS a workgroup needs 32 KiB (A only) and a wave 128 accumulators + 96 fragment
 // registers, so two workgroups share a CU -- and they are independent: the prologue (cold first DMA) and the epilogue (bias /
 // GELU / LayerNorm-fold VALU + the store burst, 15-20 % of a K = 1024 workgroup) of one run under the MFMAs of the other,
 // which the 512-register stream kernel can never do.  LDS traffic per MFMA halves (8 waves x 16 ds_read_b128 per k-tile, 32 KiB
@@ -1107,7 +1112,7 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     float* lnrow = reinterpret_cast<float*>(smem + 2 * A_BYTES);
     const int nk = g.K / BK;
     stage_ln_rows<BM, 256>(g, m0, lnrow);
-    // ---- prologue: tiles 0 and 1 of A, the weight fragments of k-step 0; drained completely (the counted waits of the
+    // ---- prologue: tiles 0 and 1 of A, the weight fragments of k-steps 0 and 1; drained completely (the counted waits of the
     // main loop are written for its steady state and are merely conservative on top of an empty queue) ----
 #pragma unroll
     for (int j = 0; j < AP; ++j) dma(j, 0);
