@@ -150,6 +150,7 @@ _DIAG_SIGNATURES = {
     "slime_attention_set_debug": (None, [c_void_p]),
     "slime_attention_set_variant": (None, [c_int]),
     "slime_prefill_set_variant": (None, [c_int]),
+    "slime_prefill_set_debug": (None, [c_void_p]),
     "slime_attention_set_ablation": (None, [c_int]),
 }
 

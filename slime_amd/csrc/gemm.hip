@@ -1111,6 +1111,9 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 
     float* lnrow = reinterpret_cast<float*>(smem + 2 * A_BYTES);
     const int nk = g.K / BK;
+#ifdef SLIME_DIAG
+    if (g.db_abl & 8) __builtin_amdgcn_s_setprio(3);
+#endif
     stage_ln_rows<BM, 256>(g, m0, lnrow);
     // ---- prologue: tiles 0 and 1 of A, the weight fragments of k-steps 0 and 1; drained completely (the counted waits of the
     // main loop are written for its steady state and are merely conservative on top of an empty queue) ----
@@ -1127,6 +1130,9 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef SLIME_DIAG
+    if (g.db_abl & 8) __builtin_amdgcn_s_setprio(0);
+#endif
     u32x4 FA[2][MI];
     auto read_frag = [&](u32x4& dstF, int i, int xbase) { dstF = *reinterpret_cast<const u32x4*>(smem + xbase + i * 2048); };
     using Yes = std::integral_constant<bool, true>;
@@ -1179,6 +1185,7 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" : "+a"(acc[i][j]));
 #ifdef SLIME_DIAG
+    if (g.db_abl & 4) __builtin_amdgcn_s_setprio(3);
     if (g.db_abl & 2) return;
     if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; }
 #endif

@@ -128,6 +128,10 @@ struct PrefillArgs {
     char* o; long o_bs, o_rs;
     const int* kv_start; const int* kv_len;     // per sequence token range, or NULL: [0, S)
     int S, group;
+    int n_kv_heads, batch;                      // prefill32_kernel's item space (its grid is a number of workgroups, not of items)
+#ifdef SLIME_DIAG
+    unsigned long long* dbg;                    // 8 counters, or NULL (prefill32.inc)
+#endif
 };
 
 __device__ __forceinline__ float quad_rows_allmax(float x) {          // max over lanes l, l+16, l+32, l+48
@@ -340,8 +344,10 @@ __global__ void __launch_bounds__(512) prefill_attn_kernel(PrefillArgs a) {
 #include "prefill32.inc"
 
 #ifdef SLIME_DIAG
-static int g_prefill_variant = 0;      // 1 = force the eight-wave kernel
+static int g_prefill_variant = 0;      // 1 = force the eight-wave kernel, 2 = prefill32 with one item per workgroup
 extern "C" void slime_prefill_set_variant(int v) { g_prefill_variant = v; }
+static unsigned long long* g_prefill_dbg = nullptr;
+extern "C" void slime_prefill_set_debug(void* counters) { g_prefill_dbg = (unsigned long long*)counters; }
 #else
 static constexpr int g_prefill_variant = 0;
 #endif
@@ -361,16 +367,23 @@ extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, cons
     SLIME_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, "prefill_attention: pointers must be 16-byte aligned");
     SLIME_REQUIRE((kv_start == nullptr) == (kv_len == nullptr), "prefill_attention: kv_start and kv_len come together");
     PrefillArgs a{(const char*)q, q_bs, q_rs, (const char*)k, k_bs, k_rs, (const char*)v, v_bs, v_rs, (char*)o, o_bs, o_rs,
-                  kv_start, kv_len, S, group};
+                  kv_start, kv_len, S, group, n_kv_heads, batch};
+#ifdef SLIME_DIAG
+    a.dbg = g_prefill_dbg;
+#endif
     hipStream_t s = (hipStream_t)stream;
-    if (group == 4 && dtype == SLIME_BF16 && g_prefill_variant == 0) {
+    if (group == 4 && dtype == SLIME_BF16 && g_prefill_variant != 1) {
         // Llama-3 geometry: one wave per SIMD, 32x32x16 MFMAs, K/V ring by LDS-DMA (prefill32.inc)
+        // (persistent over its work items: one workgroup per CU -- the 128 KiB ring allows no second one -- walks the items in
+        // snake order; diagnostic variant 2: one item per workgroup, the round-2 launch)
         constexpr int LDS32 = 2 * 8 * 32 * 256;
-        const int nqb64 = (S + 63) / 64;
-        SLIME_REQUIRE(nqb64 <= 65535, "prefill_attention: sequence too long");
+        const long items = (long)n_kv_heads * batch * ((S + 63) / 64);
+        SLIME_REQUIRE(items < (1L << 30), "prefill_attention: sequence too long");
+        const int cus = num_cus() & ~7;
+        const int grid = (g_prefill_variant == 2 || items <= cus) ? (int)items : cus;
         auto kern = prefill32_kernel<BF16>;
         SLIME_SET_LDS_ONCE(kern, LDS32, "prefill_attention");
-        hipLaunchKernelGGL(kern, dim3(n_kv_heads, batch, nqb64), dim3(256), LDS32, s, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS32, s, a);
         SLIME_CHECK_LAUNCH("prefill_attention");
         return SLIME_OK;
     }

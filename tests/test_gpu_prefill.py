@@ -275,6 +275,57 @@ def test_prefill_attention_is_deterministic(dev):
     assert torch.isfinite(outs[0].float()).all()
 
 
+@pytest.mark.parametrize("B,S", [(12, 1500), (3, 4200), (40, 200)])
+def test_prefill32_persistent_launch_equals_one_item_per_workgroup(dev, B, S):
+    """Round 3: prefill32 walks several work items (sequence, kv head, 64 query rows) per workgroup -- the K/V ring, its look-ahead
+    DMAs and the Q request run across the seam between items.  An item's arithmetic must not notice: the persistent launch is
+    BIT-equal to the diagnostic launch with one item per workgroup (the round-2 form), with token ranges that start off a step
+    boundary, end early (items with no live row get zeros and are skipped by the ring) or cover a single token, and with an odd
+    number of key steps in many items."""
+    from slime_amd import ops
+    HQ, HKV = 32, 8
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(77 + B)
+    N = (HQ + 2 * HKV) * 128
+    qkv = (torch.randn(B, S, N, generator=g) * 0.5).to(dt).to(dev)
+    qkv[..., :HQ * 128] *= 0.2
+    lib = ops._lib.load_diag()
+    st0 = [0, 37, 0, 64, S // 3, S - 1, 5, 0, 31, 33, 96, 1]
+    ln0 = [S, S - 37, S - 200 if S > 200 else S, 100, S // 2, 1, 70, 64, 1, S, 97, S - 1]
+    start = torch.tensor([st0[i % 12] for i in range(B)], dtype=torch.int32, device=dev)
+    length = torch.tensor([max(1, min(ln0[i % 12], S - st0[i % 12])) for i in range(B)], dtype=torch.int32, device=dev)
+    outs = {}
+    try:
+        for ranges in (True, False):
+            for var in (0, 2):
+                lib.slime_prefill_set_variant(var)
+                o = torch.full((B, S, HQ * 128), 7.0, dtype=dt, device=dev)
+                ops._lib.check(lib.slime_prefill_attention(qkv.data_ptr(), S * N, N, qkv.data_ptr() + HQ * 256, S * N, N,
+                                                          qkv.data_ptr() + (HQ + HKV) * 256, S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128,
+                                                          B, HQ, HKV, 128, S, start.data_ptr() if ranges else None,
+                                                          length.data_ptr() if ranges else None, ops.dtype_code(dt),
+                                                          torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                outs[(ranges, var)] = o
+            assert torch.equal(outs[(ranges, 0)], outs[(ranges, 2)])
+            assert torch.isfinite(outs[(ranges, 0)].float()).all()
+    finally:
+        lib.slime_prefill_set_variant(0)
+    # padded rows are zeros, the rest is attention (spot check of one ranged sequence against fp32 torch)
+    o = outs[(True, 0)]
+    b = 1 % B
+    lo, hi = int(start[b]), int(start[b]) + int(length[b])
+    assert float(o[b, :lo].float().abs().max() if lo else 0) == 0.0 and float(o[b, hi:].float().abs().max() if hi < S else 0) == 0.0
+    hsel = 5
+    q = qkv[b, lo:hi, hsel * 128:(hsel + 1) * 128].float() / 1.4426950408889634
+    k = qkv[b, lo:hi, (HQ + hsel // 4) * 128:(HQ + hsel // 4 + 1) * 128].float()
+    v = qkv[b, lo:hi, (HQ + HKV + hsel // 4) * 128:(HQ + HKV + hsel // 4 + 1) * 128].float()
+    causal = torch.ones(hi - lo, hi - lo, dtype=torch.bool, device=dev).tril()
+    ref = torch.softmax((q @ k.T).masked_fill(~causal, float("-inf")), -1) @ v
+    got = o[b, lo:hi, hsel * 128:(hsel + 1) * 128].float()
+    assert float((got - ref).norm() / ref.norm()) < 6e-3
+
+
 @pytest.mark.parametrize("S", [1, 5, 33, 64, 65, 127, 193])
 def test_prefill_attention_short_sequences(dev, S):
     """Sequences shorter than a workgroup's 64 query rows / not a multiple of the 32-key step, with and without a token range."""
