@@ -379,7 +379,7 @@ extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, cons
         constexpr int LDS32 = 2 * 8 * 32 * 256;
         const long items = (long)n_kv_heads * batch * ((S + 63) / 64);
         SLIME_REQUIRE(items < (1L << 30), "prefill_attention: sequence too long");
-        const int cus = num_cus() & ~7;
+        const int cus = num_cus() >= 8 ? (num_cus() & ~7) : 8;      // (a multiple of 8: the snake's mirror stays inside an XCD class)
         const int grid = (g_prefill_variant == 2 || items <= cus) ? (int)items : cus;
         auto kern = prefill32_kernel<BF16>;
         SLIME_SET_LDS_ONCE(kern, LDS32, "prefill_attention");
