@@ -595,10 +595,12 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
 // re-reads the resident panel for the remaining sub-blocks (2 or 1 per wave), with no DMA and no barrier at all.
 // The DMA is progressive: 64-row granules (one K and one V piece per wave per granule, issued in row order), and a wave
 // waits only for the granule it is about to touch (counted vmcnt + barrier), so the first MFMA starts after 16 KiB, not
-// 80 KiB, and the rest of the panel streams in under the arithmetic.
+// 80 KiB, and the rest of the panel streams in under the arithmetic -- three granules ahead of their use (round 3; requesting
+// the whole panel at once made every workgroup's first granule queue behind everybody else's panels).
 // ================================================================================================
-template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false>
-__device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0) {
+template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3>
+__device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0,
+                                             unsigned long long* t_first = nullptr) {    // diagnostic: when the first granule was ready
     constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608;
     constexpr int NG = (KC / 8 + NW - 1) / NW;            // DMA granules of NW pieces = 8 NW rows (8 waves: 10 x 64 rows, 12 waves: 7 x 96 rows;
                                                            // the last one holds 4 real pieces, rows 576..607)
@@ -610,47 +612,71 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
 
+    // K/V panel source (pass 1 only)
+    const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
+    const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
+    const int lrow = lane >> 3, cpos = lane & 7;
+    const int kchunk = cpos ^ lrow;
+    const int vchunk = cpos ^ (((lrow >> 1) & 1) << 2);
+    auto dma_granule = [&](int gi) {
+        // granule gi = pieces 8 gi .. 8 gi + 7; the last granule has 4 pieces: waves 4..7 repeat them (same bytes to the
+        // same place) so that every wave has issued exactly 2 (gi + 1) DMAs after granule gi -- the counted waits below
+        int piece = gi * NW + wave;
+        if (piece >= KC / 8) piece = KC / 8 - 4 + (wave & 3);
+        const int row = min(piece * 8 + lrow, a.n_kv - 1);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
+                                         LDS_PTR(Klds + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLOBAL_PTR(vbase + ((size_t)row * a.v_rs) * 2 + vchunk * 16),
+                                         LDS_PTR(Vlds + piece * 1024), 16, 0, 0);
+    };
     u32x4 qf[NSUB > 0 ? NSUB : 1][KS];
-    if constexpr (NSUB > 0) {
-        const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
+    const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
+    if constexpr (RESIDENT) {
+        if constexpr (NSUB > 0) {
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
+            for (int s = 0; s < NSUB; ++s) {
+                const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-                qf[s][ks] = *reinterpret_cast<const u32x4*>(qbase + ((size_t)qr * a.q_rs + ks * 32 + g * 8) * 2);
+                for (int ks = 0; ks < KS; ++ks)
+                    qf[s][ks] = *reinterpret_cast<const u32x4*>(qbase + ((size_t)qr * a.q_rs + ks * 32 + g * 8) * 2);
+            }
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[s][ks]));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // Round 3 (tools/attn64r_stamps.py): a workgroup spent 31 % of its life between its first instruction and its first K/V
+        // granule -- two memory round trips in a row (Q rows, wait, THEN the first DMA) on a CU that holds one workgroup (152 KiB
+        // of LDS) and so has nothing else to run.  Now ONE: granule 0's DMAs, the Q rows (asm loads: the compiler must not count
+        // them), the other granules -- loads return in order, so the first granule's counted wait (at most 2 (NG - 1) DMAs
+        // outstanding) covers the Q rows that sit in the queue in front of those.
+        dma_granule(0);
+        if constexpr (NSUB > 0) {
+            static_assert(KS == 2, "two 16-byte Q pieces per lane and sub-block");
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) {
+                const int qr = min((sb0 + s) * 16 + li, a.n_q - 1);
+                const char* qp = qbase + ((size_t)qr * a.q_rs + g * 8) * 2;
+                asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:64"
+                             : "=&v"(qf[s][0]), "=&v"(qf[s][1]) : "v"(qp) : "memory");
+            }
         }
 #pragma unroll
-        for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[s][ks]));
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ordinary loads retired before any LDS-DMA is in flight
-
-    if constexpr (!RESIDENT) {
-        const char* kbase = a.k + ((size_t)b * a.k_bs + (size_t)h * DH) * 2;
-        const char* vbase = a.v + ((size_t)b * a.v_bs + (size_t)h * DH) * 2;
-        const int lrow = lane >> 3, cpos = lane & 7;
-        const int kchunk = cpos ^ lrow;
-        const int vchunk = cpos ^ (((lrow >> 1) & 1) << 2);
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            // granule gi = pieces 8 gi .. 8 gi + 7; the last granule has 4 pieces: waves 4..7 repeat them (same bytes to the
-            // same place) so that every wave has issued exactly 2 (gi + 1) DMAs after granule gi -- the counted waits below
-            int piece = gi * NW + wave;
-            if (piece >= KC / 8) piece = KC / 8 - 4 + (wave & 3);
-            const int row = min(piece * 8 + lrow, a.n_kv - 1);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
-                                             LDS_PTR(Klds + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(vbase + ((size_t)row * a.v_rs) * 2 + vchunk * 16),
-                                             LDS_PTR(Vlds + piece * 1024), 16, 0, 0);
-        }
+        for (int gi = 1; gi < NG && gi < AHEAD; ++gi) dma_granule(gi);
     }
     // granule gi has landed for THIS wave when at most 2 (NG - 1 - gi) of its DMAs are outstanding; the barrier extends that
     // to every wave's pieces.  Called by every wave of the workgroup for gi = 0, 1, 2, ... in order (uniform control flow).
+    // Only AHEAD granules are requested up front, granule gi + AHEAD behind the barrier of granule gi.  Round 3
+    // (tools/attn64r_stamps.py, profiles/r03_attn64r_depth.txt): with the whole panel requested at once (rounds 1-2) a workgroup
+    // spent 31 % of its life waiting for its FIRST granule -- behind the up-to-152 KiB the other CUs of its XCD had queued each;
+    // with 3 ahead the queues are shallow: start-up 13.4 k -> 7.3 k ticks, the steps themselves 6 % faster, kernel 61.4 -> 53.2 us
+    // at 20 crops, 105 -> 94 at 40, 18.6 -> 17.4 at 5; bit-equal (same arithmetic, same LDS layout).  2 ahead measures the same.
     auto granule_ready = [&](int gi) {
         if constexpr (!RESIDENT) {
-            switch (NG - 1 - gi) {                          // granules still allowed in flight
+            const int fly = min(AHEAD - 1, NG - 1 - gi);        // granules still allowed in flight
+            switch (fly) {
                 case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
                 case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
                 case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
@@ -665,6 +691,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AHEAD < NG) { if (gi + AHEAD < NG) dma_granule(gi + AHEAD); }
         }
     };
     auto before_step = [&](int st) { if (st % SPG == 0) granule_ready(st / SPG); };   // step st reads rows 32 st .. 32 st + 31
@@ -798,6 +825,13 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
         const bool ragged = (a.n_kv & 31) != 0;
         // step st's K rows must have landed before they are REQUESTED, i.e. one qk() call earlier than they are multiplied
         before_step(0);
+        if constexpr (!RESIDENT) {                           // (the Q rows landed with granule 0)
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s) asm volatile("" : "+v"(qf[s][0]), "+v"(qf[s][1]));
+        }
+#ifdef SLIME_DIAG
+        if (t_first) *t_first = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (KPF) k_request();                      // step 0
         if (steps > 1) before_step(1);
         qk(sA, steps > 1);                                   // multiplies step 0, requests step 1
@@ -836,7 +870,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
     }
 }
 
-template <typename T>
+template <typename T, int AHEAD = 3>
 __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 8, P1 = 3 * NW;                        // pass 1: <= 3 sub-blocks per wave
@@ -846,17 +880,27 @@ __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
     const int wg_sb0 = blockIdx.z * a.sb_per_wg;
     const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);      // <= 5 * NW
     const int n1 = min(nsb, P1), n2 = nsb - n1;               // pass 2: <= 2 per wave
+#ifdef SLIME_DIAG
+    // diagnostic variant 17: a.dbg holds one record of 8 words per workgroup (s_memtime stamps of wave 0)
+    unsigned long long dt0 = __builtin_amdgcn_s_memtime(), dtf = dt0;
+    unsigned long long* tfp = a.dbg ? &dtf : nullptr;
+#else
+    constexpr unsigned long long* tfp = nullptr;
+#endif
     {
         const int base = n1 / NW, rem = n1 % NW;
         const int cnt = base + (wave < rem ? 1 : 0);
         const int sb0 = wg_sb0 + wave * base + min(wave, rem);
         switch (cnt) {
-            case 0: attn64r_pass<T, 0, false>(a, smem, b, h, sb0); break;
-            case 1: attn64r_pass<T, 1, false>(a, smem, b, h, sb0); break;
-            case 2: attn64r_pass<T, 2, false>(a, smem, b, h, sb0); break;
-            default: attn64r_pass<T, 3, false>(a, smem, b, h, sb0); break;
+            case 0: attn64r_pass<T, 0, false, NW, false, AHEAD>(a, smem, b, h, sb0); break;
+            case 1: attn64r_pass<T, 1, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
+            case 2: attn64r_pass<T, 2, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
+            default: attn64r_pass<T, 3, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
         }
     }
+#ifdef SLIME_DIAG
+    const unsigned long long dt1 = __builtin_amdgcn_s_memtime();
+#endif
     if (n2 > 0) {
         // every wave left pass 1 behind the last granule's barrier: the whole panel is resident and read-only from here on.
         // The waves that got the most work in pass 1 (low ids when n1 % 8 != 0) get the least here.
@@ -870,6 +914,15 @@ __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
             default: attn64r_pass<T, 2, true>(a, smem, b, h, sb0); break;
         }
     }
+#ifdef SLIME_DIAG
+    if (a.dbg && threadIdx.x == 0) {                          // one record per workgroup (wave 0): entry, first granule, end of pass 1, end, where
+        const unsigned long long dt2 = __builtin_amdgcn_s_memtime();
+        unsigned long long* r = a.dbg + 8 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        r[0] = dt0; r[1] = dtf; r[2] = dt1; r[3] = dt2;
+        r[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)) |
+               ((unsigned long long)__builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)) << 32);
+    }
+#endif
 }
 
 // Twelve-wave variant: three waves per SIMD (<= 2 sub-blocks each, <= 168 VGPRs) instead of two with three sub-blocks.
@@ -909,11 +962,11 @@ static int launch_attn64w(const AttnArgs& a0, int batch, hipStream_t stream) {
     return SLIME_OK;
 }
 
-template <typename T>
+template <typename T, int AHEAD = 3>
 static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
     constexpr int LDS = 2 * 608 * 128;
-    auto kern = attn64r_kernel<T>;
+    auto kern = attn64r_kernel<T, AHEAD>;
     SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
     int qsplit = (total_sb + 39) / 40;                        // <= 3 + 2 sub-blocks per wave, 8 waves
@@ -989,6 +1042,20 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
         return launch_attn32<BF16>(a, batch, g_attn_variant == 5 ? 2 : g_attn_variant == 6 ? -1 : 0, s);
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant >= 12 && g_attn_variant <= 15 && dtype == SLIME_BF16)
         return launch_attn32<BF16>(a, batch, g_attn_variant - 10, s);                       // every item cut in 2 / 3 / 4 / 5
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant >= 22 && g_attn_variant <= 27 && dtype == SLIME_BF16) {
+        // attn64r with 2 / 3 / 4 / 6 K/V granules requested ahead, 27: the whole panel up front (rounds 1-2); with or without stamp records
+        switch (g_attn_variant) {
+            case 22: return launch_attn64r<BF16, 2>(a, batch, s);
+            case 23: return launch_attn64r<BF16, 3>(a, batch, s);
+            case 24: return launch_attn64r<BF16, 4>(a, batch, s);
+            case 26: return launch_attn64r<BF16, 6>(a, batch, s);
+            default: return launch_attn64r<BF16, 16>(a, batch, s);
+        }
+    }
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 17 && g_attn_dbg) {   // attn64r with one stamp record per workgroup
+        if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
+        return launch_attn64r<BF16>(a, batch, s);
+    }
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 7 && !g_attn_dbg) {    // round 2's product kernel, for A/B
         if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
         return launch_attn64r<BF16>(a, batch, s);
