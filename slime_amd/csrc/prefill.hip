@@ -381,6 +381,15 @@ extern "C" int slime_prefill_attention(const void* q, long q_bs, long q_rs, cons
         SLIME_REQUIRE(items < (1L << 30), "prefill_attention: sequence too long");
         const int cus = num_cus() >= 8 ? (num_cus() & ~7) : 8;      // (a multiple of 8: the snake's mirror stays inside an XCD class)
         const int grid = (g_prefill_variant == 2 || items <= cus) ? (int)items : cus;
+#ifdef SLIME_DIAG
+        if (g_prefill_variant == 3) {                            // look-ahead of 4 key steps instead of 6
+            auto kern4 = prefill32_kernel<BF16, 4>;
+            SLIME_SET_LDS_ONCE(kern4, LDS32, "prefill_attention");
+            hipLaunchKernelGGL(kern4, dim3(grid), dim3(256), LDS32, s, a);
+            SLIME_CHECK_LAUNCH("prefill_attention");
+            return SLIME_OK;
+        }
+#endif
         auto kern = prefill32_kernel<BF16>;
         SLIME_SET_LDS_ONCE(kern, LDS32, "prefill_attention");
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS32, s, a);

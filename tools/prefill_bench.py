@@ -9,7 +9,7 @@ from slime_amd import ops, _lib
 dev = torch.device("cuda:0"); lib = _lib.load_diag(); dt = torch.bfloat16
 HQ, HKV = 32, 8
 N = (HQ + 2 * HKV) * 128
-NAMES = {0: 'prefill32 persistent', 2: 'prefill32 1 item/wg ', 1: 'eight-wave          '}
+NAMES = {0: 'prefill32 persistent', 3: 'prefill32 4 ahead   ', 2: 'prefill32 1 item/wg ', 1: 'eight-wave          '}
 for B, S in ((8, 1216), (1, 9280), (4, 4096), (2, 1216), (8, 700)):
     qkv = (torch.randn(B, S, N, device=dev) * 0.5).to(dt); qkv[..., :HQ * 128] *= 0.1
     o = torch.empty((B, S, HQ * 128), dtype=dt, device=dev)
@@ -20,7 +20,7 @@ for B, S in ((8, 1216), (1, 9280), (4, 4096), (2, 1216), (8, 700)):
     outs = {}
     fl = 4.0 * B * HQ * (S * (S + 1) / 2) * 128
     for rnd in range(2):
-        for var in (0, 2, 1):
+        for var in (0, 3, 2, 1):
             lib.slime_prefill_set_variant(var)
             for _ in range(3): run()
             torch.cuda.synchronize()
@@ -32,5 +32,5 @@ for B, S in ((8, 1216), (1, 9280), (4, 4096), (2, 1216), (8, 700)):
             outs[var] = o.clone()
             print(f"B={B} S={S} {NAMES[var]}: {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s", flush=True)
     d = (outs[0].float() - outs[1].float()).norm() / outs[1].float().norm()
-    print(f"   rel-L2 prefill32 vs eight-wave: {float(d):.2e}; persistent bit-equal to one item per workgroup: {bool(torch.equal(outs[0], outs[2]))}")
+    print(f"   rel-L2 prefill32 vs eight-wave: {float(d):.2e}; persistent bit-equal to one item per workgroup: {bool(torch.equal(outs[0], outs[2]))}, to 4 steps ahead: {bool(torch.equal(outs[0], outs[3]))}")
 lib.slime_prefill_set_variant(0)
