@@ -327,7 +327,7 @@ def tower_kernel_names(pt: PackedTower, n_crops: int) -> Dict[int, str]:
     t = "F16" if pt.dtype == torch.float16 else "BF16"
     fr = {k: pt.tensors.get(k + "_frag") is not None for k in ("w_qkv", "w_o", "w_fc1", "w_fc2")}
     return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T, fr["w_qkv"]),
-            2: f"attn64r_kernel<{t}>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
+            2: f"attn64r_kernel<{t}, 3>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
             5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T, fr["w_fc1"]),
             3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_o"]),
             6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_fc2"])}
