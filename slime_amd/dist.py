@@ -36,7 +36,8 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
 # Tower latency on one MI355X, bf16, one encode() call over n crops (tools/stream_split_sweep.py, tools/rank_shapes.py;
 # profiles/r03_stream_split_sweep.txt): a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us
 # kernels) and ~0.33 ms per crop beyond ~16 crops, where the GEMM grids fill the chip.  From 8 crops on encode() runs two half batches
-# on two streams (the step between 7 and 8 crops is the out_proj / fc2 grid crossing one workgroup per CU).
+# on two streams (the step between 7 and 8 crops is the out_proj / fc2 grid crossing one workgroup per CU).  (Measured before the round's last
+# kernel change -- attention K/V requests three granules ahead, 1.2 us per launch at 5 crops, 7-8 us at 20 -- i.e. 1-2 % pessimistic now.)
 TOWER_MS = {1: 2.40, 2: 2.55, 3: 2.75, 4: 2.93, 5: 3.15, 6: 3.31, 7: 3.56, 8: 4.38, 9: 4.45, 10: 4.74, 12: 5.39, 14: 5.94, 16: 6.77,
             17: 7.05, 20: 8.11, 24: 9.32, 28: 10.54, 34: 13.21, 40: 15.22}
 
