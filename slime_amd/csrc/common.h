@@ -40,6 +40,14 @@ struct BF16 {
     static __device__ __forceinline__ void mfma16_vgpr(f32x4& acc, u32x4 a, u32x4 b) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
     }
+    // first k-step of an output tile: C = 0 (inline constant), the accumulator is written, not read
+    static __device__ __forceinline__ void mfma16_agpr_init(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+    }
+    // last k-step of an output tile in a kernel that drains a second accumulator set: D = C + A B (vdst != srcC)
+    static __device__ __forceinline__ void mfma16_agpr_fin(f32x4& d, const f32x4& c, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, %1" : "=a"(d) : "a"(c), "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};
         return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // RNE
@@ -62,6 +70,14 @@ struct F16 {
     }
     static __device__ __forceinline__ void mfma16_vgpr(f32x4& acc, u32x4 a, u32x4 b) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    }
+    // first k-step of an output tile: C = 0 (inline constant), the accumulator is written, not read
+    static __device__ __forceinline__ void mfma16_agpr_init(f32x4& acc, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+    }
+    // last k-step of an output tile in a kernel that drains a second accumulator set: D = C + A B (vdst != srcC)
+    static __device__ __forceinline__ void mfma16_agpr_fin(f32x4& d, const f32x4& c, u32x4 a, u32x4 b) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %2, %3, %1" : "=a"(d) : "a"(c), "v"(a), "v"(b));
     }
     static __device__ __forceinline__ unsigned pack2(float lo, float hi) {
         f32x2 v = {lo, hi};

@@ -69,6 +69,17 @@ __device__ __forceinline__ float rows4_allsum(float x) {
 // partial sums (sum x, sum x^2 per 64-column group, summed here in a FIXED order: results do not depend on the tile shape
 // of either kernel).  Ordinary loads, issued before any LDS-DMA of the prologue.  var = E[x^2] - mu^2 in fp32: sound while
 // |mu| is not orders of magnitude above sigma (residual streams are not; tests/test_gpu_path.py stresses x100 outliers).
+// (sum x, sum x^2) of a K-wide row -> (rstd, -mu rstd).  One shared definition with the operations written out (no contraction left
+// to the compiler's discretion): every kernel family finalises the statistics to the same bits.
+__device__ __forceinline__ void ln_finalize(float sx, float sq, int K, float eps, float& rstd, float& nmr) {
+    const float inv = 1.0f / (float)K;
+    const float mu = __fmul_rn(sx, inv);
+    const float m2 = __fmul_rn(mu, mu);
+    const float var = fmaxf(__fmaf_rn(sq, inv, -m2), 0.f);
+    rstd = rsqrtf(var + eps);
+    nmr = __fmul_rn(-mu, rstd);
+}
+
 template <int BM, int NT>
 __device__ __forceinline__ void stage_ln_rows(const GemmArgs& g, const int m0, float* lnrow) {
     if (!g.ln_stats) return;
@@ -87,11 +98,7 @@ __device__ __forceinline__ void stage_ln_rows(const GemmArgs& g, const int m0, f
             } else {
                 for (int i = 0; i < g.ln_groups; ++i) { const float2 v = st[i]; sx += v.x; sq += v.y; }
             }
-            const float inv = 1.0f / (float)g.K;
-            const float mu = sx * inv;
-            const float var = fmaxf(sq * inv - mu * mu, 0.f);
-            rstd = rsqrtf(var + g.ln_eps);
-            nmr = -mu * rstd;
+            ln_finalize(sx, sq, g.K, g.ln_eps, rstd, nmr);
         }
         lnrow[2 * r] = rstd; lnrow[2 * r + 1] = nmr;
     }
@@ -1209,6 +1216,13 @@ __global__ void __launch_bounds__(256) pack_b_frag_kernel(const u32x4* __restric
     out[o] = B[((size_t)n * K + 32 * s + 8 * (lane >> 4)) / 8];
 }
 
+#ifdef SLIME_DIAG
+// Round 4's persistent direct-B kernels with the epilogue in the next tile's MFMA stream: bit-identical to the kernels above,
+// measured SLOWER than gemm_db_kernel (profiles/r04_ps_ablation.txt) -- kept as measured alternatives, tiles 16 / 17.
+#include "gemm_ps32.inc"
+#include "gemm_ps.inc"
+#endif
+
 #ifdef SLIME_DIAG   // measured alternatives: compiled into libslime_hip_diag.so only
 // ================================================================================================
 // Persistent ping-pong kernel: the ping-pong kernel above, but a workgroup walks its output tiles
@@ -1785,6 +1799,61 @@ static int launch_db(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_db_k<T, EPI, 1, MI>(g, stream) : launch_db_k<T, EPI, 0, MI>(g, stream);
 }
 
+#ifdef SLIME_DIAG
+// Persistent direct-B kernels (gemm_ps32.inc, gemm_ps.inc; diagnostic build): one workgroup per CU, LDS = 4 A stages + 2 row
+// tables + bias / colsum of the launch
+static bool ps_usable(const GemmArgs& g, int epi) {
+    const long cus = num_cus();
+    const long nblk = (long)((g.M + 127) / 128) * (g.N / 256);
+    return g.Bf && g.N % 256 == 0 && g.N <= 8192 && g.K == 1024 && g.ln_stats && g.ln_groups == 16 && g.ln_colsum &&
+           (epi == SLIME_EPI_BIAS_T || epi == SLIME_EPI_BIAS_QUICKGELU_T) && cus % 8 == 0 && nblk >= 2 * cus &&
+           (size_t)g.M * g.ldc * 2 < (1ull << 31) && (size_t)128 * g.lda * 2 < (1ull << 32);
+}
+#define PS_LAUNCH(KERN)                                                                                              \
+    do {                                                                                                             \
+        auto kern_ = KERN;                                                                                           \
+        SLIME_SET_LDS_ONCE(kern_, LDS_FIXED + 2 * 8192 * 4, "gemm_ps");                                              \
+        hipLaunchKernelGGL(kern_, dim3(num_cus()), dim3(256), LDS_FIXED + 2 * g.N * 4, stream, g);                   \
+        SLIME_CHECK_LAUNCH("gemm_ps");                                                                               \
+        return SLIME_OK;                                                                                             \
+    } while (0)
+template <typename T, int EPI>
+static int launch_ps32(const GemmArgs& g, hipStream_t stream) {
+    if constexpr (EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+        constexpr int LDS_FIXED = 4 * 128 * 64 * 2 + 2 * 128 * 8;
+        // slime_gemm_set_db_ablation(16 + DBG): 17 = every counted wait drained; 18 / 20 / 22 / 30 = timing-only ablations
+        if constexpr (T::id == SLIME_BF16 && EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+            if (g.db_abl == 17) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 1>));
+            if (g.db_abl == 18) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 2>));
+            if (g.db_abl == 20) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 4>));
+            if (g.db_abl == 22) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6>));
+            if (g.db_abl == 30) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 14>));
+            if (g.db_abl == 38) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16>));          // + no weight requests
+            if (g.db_abl == 54) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 32>));          // + no LDS-DMA
+            if (g.db_abl == 70) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16 + 32>));     // + neither
+            if (g.db_abl == 134) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16 + 32 + 64>)); // + no fragment reads: MFMAs + scalar bookkeeping
+        }
+        PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16>));
+    } else {
+        slime_set_error("gemm_ps32: epilogue %d has no persistent form", EPI);
+        return SLIME_EINVAL;
+    }
+}
+template <typename T, int EPI>
+static int launch_ps16(const GemmArgs& g, hipStream_t stream) {
+    if constexpr ((EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T) && T::id == SLIME_BF16) {
+        constexpr int LDS_FIXED = 4 * 128 * 64 * 2 + 2 * 128 * 8;
+        if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+            if (g.db_abl == 18) PS_LAUNCH((gemm_ps_kernel<T, EPI, 16, 2>));
+        }
+        PS_LAUNCH((gemm_ps_kernel<T, EPI, 16>));
+    } else {
+        return launch_ps32<T, EPI>(g, stream);
+    }
+}
+#undef PS_LAUNCH
+#endif
+
 template <typename T, int EPI>
 static int launch_pp192(const GemmArgs& g, hipStream_t stream) {
     return g.K >= 2048 ? launch_pp_k<T, EPI, 1, 0, 3>(g, stream) : launch_pp_k<T, EPI, 0, 0, 3>(g, stream);
@@ -1879,6 +1948,12 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 9) return launch_pp192<T, EPI>(g, stream);
     if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
     if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
+#endif
+#ifdef SLIME_DIAG
+    if (tile == 16 || tile == 17) {                                        // persistent direct-B, measured alternatives: 16 = 16x16x32 MFMAs, 17 = 32x32x16
+        if (ps_usable(g, EPI)) return tile == 16 ? launch_ps16<T, EPI>(g, stream) : launch_ps32<T, EPI>(g, stream);
+        tile = g.Bf ? 12 : 11;
+    }
 #endif
     if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);

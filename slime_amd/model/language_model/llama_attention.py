@@ -61,18 +61,69 @@ class HipLlamaAttention(nn.Module):
         return out, None, None
 
 
+def _rope_theta(cfg) -> float:
+    """rope_theta of a LlamaConfig across transformers versions (4.x attribute, 5.x ``rope_parameters`` dict); only the default
+    rotary embedding is implemented in the kernel (``slime_rope``: inv_freq = theta^(-2i/d), as Llama-3-8B / SliME-8B use)."""
+    rp = getattr(cfg, "rope_parameters", None)
+    scaling = getattr(cfg, "rope_scaling", None) or (rp if isinstance(rp, dict) else None)
+    if isinstance(scaling, dict):
+        kind = scaling.get("rope_type", scaling.get("type", "default"))
+        if kind not in (None, "default"):
+            raise NotImplementedError(f"slime_amd's prefill attention implements the default rotary embedding, not rope_type={kind!r}")
+    if isinstance(rp, dict) and rp.get("rope_theta") is not None:
+        return float(rp["rope_theta"])
+    return float(getattr(cfg, "rope_theta", 500000.0))
+
+
+def _self_attn_return_arity(M) -> int:
+    """How many values ``LlamaDecoderLayer.forward`` unpacks from ``self.self_attn(...)``: 3 in transformers <= 4.47 (attn output,
+    weights, present key/value -- the reference's pin 4.37.2, llama_flash_attn_monkey_patch.py:92), 2 from 4.48 on."""
+    import inspect
+    import re
+    try:
+        src = inspect.getsource(M.LlamaDecoderLayer.forward)
+        m = re.search(r"([\w\s,]+?)=\s*self\.self_attn\(", src)
+        if m:
+            return len([t for t in m.group(1).split(",") if t.strip()])
+    except (OSError, TypeError):
+        pass
+    import transformers
+    major, minor = (int(x) for x in transformers.__version__.split(".")[:2])
+    return 2 if (major, minor) >= (4, 48) else 3
+
+
+_PATCH_STATE: Dict[str, object] = {}
+
+
 def replace_llama_attn_with_hip_attn():
-    """Patch HF ``LlamaAttention.forward`` like ``replace_llama_attn_with_flash_attn`` does (the key-padding mask must reach
-    the attention un-expanded, as in the reference's ``_prepare_decoder_attention_mask`` override)."""
+    """Patch HF ``LlamaAttention.forward`` like ``replace_llama_attn_with_flash_attn`` does (llama_flash_attn_monkey_patch.py:105-115),
+    for whichever transformers is installed:
+
+      * the forward accepts the keyword set of every generation (``position_ids``, ``past_key_value`` / ``past_key_values``,
+        ``position_embeddings``, ``cache_position`` ...) and returns as many values as the installed ``LlamaDecoderLayer`` unpacks
+        (3 up to 4.47, 2 from 4.48 on);
+      * the [B, S] key-padding mask must reach the attention un-expanded, as in the reference's ``_prepare_decoder_attention_mask``
+        override (:97-102): 4.37 keeps that hook; 4.38-4.52 build the 4-D mask in ``LlamaModel._update_causal_mask``; later
+        versions call the module-level ``create_causal_mask`` -- each is replaced by a pass-through of the 2-D mask.
+
+    Returns the ``transformers`` module; ``restore_llama_attn()`` undoes the patch."""
     import transformers
     from transformers.models.llama import modeling_llama as M
+    arity = _self_attn_return_arity(M)
 
-    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
-                use_cache=False, **kw):
+    def forward(self, hidden_states, *args, attention_mask=None, position_ids=None, past_key_value=None, past_key_values=None,
+                output_attentions=False, use_cache=False, **kw):
+        # positional forms of the old signature (hidden_states, attention_mask, position_ids, past_key_value, ...)
+        if len(args) > 0 and attention_mask is None and not isinstance(args[0], tuple):
+            attention_mask = args[0]
+        if len(args) > 1 and position_ids is None:
+            position_ids = args[1]
         # prefill only: HF generate() defaults to use_cache=True -- call the patched model with use_cache=False (a present
         # k/v return for the prefill step would be the natural extension; decode is outside SURVEY section 8)
-        if past_key_value is not None or kw.get("past_key_values") is not None or use_cache:
+        if past_key_value is not None or past_key_values is not None or use_cache:
             raise NotImplementedError("slime_amd patches the prefill pass only: pass use_cache=False (no KV cache on this path)")
+        if output_attentions:
+            raise NotImplementedError("the fused prefill attention never materialises the attention weights")
         cfg = self.config
         key = "_slime_packed"
         dt = hidden_states.dtype if hidden_states.dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
@@ -85,13 +136,39 @@ def replace_llama_attn_with_hip_attn():
             cache.clear()
             cache[k] = ops.pack_llama_attention(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.o_proj.weight,
                                                 cfg.num_attention_heads, cfg.num_key_value_heads, dt, self.q_proj.weight.device,
-                                                float(getattr(cfg, "rope_theta", 500000.0)))
+                                                _rope_theta(cfg))
         if attention_mask is not None and attention_mask.dim() != 2:
-            raise ValueError("expected the [B, S] key-padding mask (llama_flash_attn_monkey_patch.py:97-102)")
+            raise ValueError("expected the [B, S] key-padding mask (llama_flash_attn_monkey_patch.py:97-102): the model-level mask "
+                             "builder of this transformers version is not patched through")
         out = ops.llama_attention_forward(cache[k], hidden_states, position_ids, attention_mask, hidden_states.dtype)
-        return out, None, None
+        return (out, None) if arity == 2 else (out, None, None)
 
-    if hasattr(M.LlamaModel, "_prepare_decoder_attention_mask"):
+    if not _PATCH_STATE:
+        _PATCH_STATE["forward"] = M.LlamaAttention.forward
+        for name in ("_prepare_decoder_attention_mask", "_update_causal_mask"):
+            if hasattr(M.LlamaModel, name):
+                _PATCH_STATE["model." + name] = getattr(M.LlamaModel, name)
+        if hasattr(M, "create_causal_mask"):
+            _PATCH_STATE["module.create_causal_mask"] = M.create_causal_mask
+    if hasattr(M.LlamaModel, "_prepare_decoder_attention_mask"):                 # <= 4.37: the reference's own hook
         M.LlamaModel._prepare_decoder_attention_mask = lambda self, attention_mask, *a, **k: attention_mask
+    if hasattr(M.LlamaModel, "_update_causal_mask"):                             # 4.38 ... 4.52
+        M.LlamaModel._update_causal_mask = lambda self, attention_mask, *a, **k: attention_mask
+    if hasattr(M, "create_causal_mask"):                                         # >= 4.53: LlamaModel.forward looks the name up in its module
+        M.create_causal_mask = lambda *a, attention_mask=None, **k: attention_mask
     M.LlamaAttention.forward = forward
     return transformers
+
+
+def restore_llama_attn():
+    """Undo ``replace_llama_attn_with_hip_attn`` (tests run patched and stock models in one process)."""
+    if not _PATCH_STATE:
+        return
+    from transformers.models.llama import modeling_llama as M
+    M.LlamaAttention.forward = _PATCH_STATE["forward"]
+    for k, v in _PATCH_STATE.items():
+        if k.startswith("model."):
+            setattr(M.LlamaModel, k[6:], v)
+        elif k.startswith("module."):
+            setattr(M, k[7:], v)
+    _PATCH_STATE.clear()

@@ -101,13 +101,23 @@ def _fused_adapter(model, images: torch.Tensor, layout, out_dtype: torch.dtype, 
                                int(model.mm_projector.learnable_gated), out_dtype, out)
 
 
-def splice_plan(input_ids, attention_mask, labels, feat_lens, max_length=None, padding_side: str = "right"):
+def _check_token_ids(t, vocab_size):
+    """nn.Embedding raises IndexError for an id outside [0, vocab); the splice would instead read id -1 as padding and an id
+    <= -2 as an image-feature row.  IMAGE_TOKEN_INDEX is the one legal negative id."""
+    import numpy as np
+    bad = (t != IMAGE_TOKEN_INDEX) & ((t < 0) | (t >= vocab_size))
+    if bad.any():
+        raise IndexError(f"input_ids contain token id {int(t[np.argmax(bad)])} outside [0, {vocab_size}) (index out of range in self)")
+
+
+def splice_plan(input_ids, attention_mask, labels, feat_lens, max_length=None, padding_side: str = "right", vocab_size=None):
     """Index plan of ``prepare_inputs_labels_for_multimodal`` (llava_arch.py:362-459), integer host logic on numpy arrays.
     ``input_ids`` [B, L] int64 (IMAGE_TOKEN_INDEX marks an image), ``attention_mask`` [B, L] or None, ``labels`` [B, L] or
     None, ``feat_lens[j]`` = token rows of image feature j (consumed in order of appearance; a sequence without an image
     token still consumes one feature, of which it uses zero rows: :377-385).
     Returns int64 arrays [B, max_len]: ``src`` (>= 0 token id, -2 - k row k of the concatenated features, -1 padding),
-    ``labels`` (IGNORE_INDEX on image and padding rows), ``mask``, ``position_ids``."""
+    ``labels`` (IGNORE_INDEX on image and padding rows), ``mask``, ``position_ids``.
+    ``vocab_size``: validate the ids that survive the mask (the only ones the reference embeds, :361-373) as nn.Embedding would."""
     import numpy as np
     ids = np.asarray(input_ids, dtype=np.int64)
     B = ids.shape[0]
@@ -117,6 +127,8 @@ def splice_plan(input_ids, attention_mask, labels, feat_lens, max_length=None, p
     seqs, labs, img = [], [], 0
     for b in range(B):
         t, y = ids[b][am[b]], lb[b][am[b]]                                  # :366-368 drop padding through the mask
+        if vocab_size is not None:
+            _check_token_ids(t, vocab_size)
         where = np.nonzero(t == IMAGE_TOKEN_INDEX)[0]
         if where.size == 0:                                                 # :376-385
             if img >= len(feat_lens):
@@ -313,13 +325,15 @@ class SlimeMetaForCausalLM(ABC):
         if vision_tower is None or images is None or input_ids.shape[1] == 1:
             return input_ids, position_ids, attention_mask, past_key_values, None, labels
         merge_type = getattr(self.config, "mm_patch_merge_type", "flat")
-        # The ids come to the host once (the splice plan below is integer host logic).  A token id beyond the embedding table is
-        # rejected HERE, before anything touches the device: the reference's nn.Embedding lookups (llava_arch.py:373, :392 and the
-        # router's text embedding) would hit a device-side assert, which on ROCm aborts the process instead of raising.
+        # The ids come to the host once (the splice plan below is integer host logic).  A token id outside the embedding table is
+        # rejected HERE, before anything touches the device: the reference's nn.Embedding lookups would hit a device-side assert,
+        # which on ROCm aborts the process instead of raising.  Scope as in the reference: the splice embeds only the ids under the
+        # attention mask (llava_arch.py:361-373: a pad id past the table is legal there) -- splice_plan checks those --, the
+        # text-guided router embeds EVERY non-image id, padding included (get_pure_text_embedding, :162-179).
         ids_np = input_ids.detach().cpu().numpy()
         vocab = self.get_model().embed_tokens.weight.shape[0]
-        if ids_np.size and int(ids_np.max()) >= vocab:
-            raise IndexError(f"input_ids contain token id {int(ids_np.max())} >= vocabulary size {vocab} (index out of range in self)")
+        if getattr(self.get_model(), "has_sampler", False) and ids_np.size:
+            _check_token_ids(ids_np.reshape(-1), vocab)
         if type(images) is list or images.ndim == 5:
             if type(images) is list:
                 images = [x.unsqueeze(0) if x.ndim == 3 else x for x in images]
@@ -354,7 +368,7 @@ class SlimeMetaForCausalLM(ABC):
                                           None if attention_mask is None else attention_mask.detach().cpu().numpy(),
                                           None if labels is None else labels.detach().cpu().numpy(),
                                           [f.shape[0] for f in feats], getattr(self.config, "tokenizer_model_max_length", None),
-                                          getattr(self.config, "tokenizer_padding_side", "right"))
+                                          getattr(self.config, "tokenizer_padding_side", "right"), vocab_size=vocab)
         B, T = src.shape
         allf = torch.cat([f.reshape(-1, f.shape[-1]) for f in feats], 0).to(dev) if feats else None
         out_dtype = table.dtype if table.dtype in (torch.float32, torch.bfloat16, torch.float16) else torch.float32

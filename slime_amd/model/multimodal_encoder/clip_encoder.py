@@ -141,23 +141,24 @@ class HipCLIPVisionModel(nn.Module):
             split = self.force_streams == 2 and n >= 2
         if not split:
             return ops.tower_forward(self.packed(select_layer), pixel_values, out_dtype, keep_cls)
-        # two independent half batches on two streams: fills each kernel's last partial round
+        # two independent half batches on two streams: fills each kernel's last partial round.  The first half stays on the CALLER's
+        # stream, only the second gets a stream of its own: ROCm maps HIP streams onto 4 hardware queues by default, and with two
+        # private tower streams + the caller's + a tail stream + RCCL's, the two halves landed on ONE queue and serialised (round 4:
+        # the forced-collective bench line lost 15 % that way, profiles/r04_collective_hw_queues.txt).
         if self._streams is None:
-            self._streams = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)]
+            self._streams = [torch.cuda.Stream(device=self.device)]
         cur = torch.cuda.current_stream()
+        side = self._streams[0]
         half = (n + 1) // 2
         rows = self.config.num_patches + (1 if keep_cls else 0)
         out = torch.empty((n, rows, self.config.hidden_size), dtype=out_dtype, device=pixel_values.device)
-        parts = ((pixel_values[:half], out[:half]), (pixel_values[half:], out[half:]))
-        for slot, (s, (p, o)) in enumerate(zip(self._streams, parts)):
-            s.wait_stream(cur)
-            with torch.cuda.stream(s):
-                ops.tower_forward(self.packed(select_layer, slot), p, out_dtype, keep_cls, out=o)   # both halves land in one tensor
-            p.record_stream(s)
-        out.record_stream(self._streams[0])
-        out.record_stream(self._streams[1])
-        for s in self._streams:
-            cur.wait_stream(s)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            ops.tower_forward(self.packed(select_layer, 1), pixel_values[half:], out_dtype, keep_cls, out=out[half:])
+        ops.tower_forward(self.packed(select_layer, 0), pixel_values[:half], out_dtype, keep_cls, out=out[:half])   # both halves land in one tensor
+        pixel_values.record_stream(side)
+        out.record_stream(side)
+        cur.wait_stream(side)
         return out
 
     @torch.no_grad()

@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -761,11 +763,24 @@ class PackedLlamaAttention:
     @property
     def ws(self) -> Workspace:
         """The layers of a language model run one after the other on one stream: they share ONE grow-only scratch buffer per
-        device (a Workspace per packed layer kept 32 x ~200 MB alive at the SliME-8B prefill shapes)."""
-        return _LLAMA_WS
+        (device, stream) (a Workspace per packed layer kept 32 x ~200 MB alive at the SliME-8B prefill shapes).  Keyed on the
+        CURRENT stream: two models / requests prefilling on different streams (or devices) never write the same scratch, and a
+        model split across GPUs keeps one buffer per device instead of re-allocating at every device switch."""
+        return _llama_workspace()
 
 
-_LLAMA_WS = Workspace()
+_LLAMA_WS: Dict[tuple, Workspace] = {}
+_LLAMA_WS_LOCK = threading.Lock()
+
+
+def _llama_workspace() -> Workspace:
+    st = torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    with _LLAMA_WS_LOCK:
+        ws = _LLAMA_WS.get(key)
+        if ws is None:
+            ws = _LLAMA_WS[key] = Workspace()
+        return ws
 
 
 def llama_inv_freq(head_dim: int, theta: float) -> torch.Tensor:
@@ -795,6 +810,7 @@ def pack_llama_attention(wq, wk, wv, wo, n_heads: int, n_kv_heads: int, dtype: t
 
 
 _RANGE_CACHE: Dict[str, object] = {}
+_RANGE_LOCK = threading.Lock()
 
 
 def token_ranges(attention_mask: Optional[torch.Tensor]):
@@ -805,10 +821,13 @@ def token_ranges(attention_mask: Optional[torch.Tensor]):
     version counter; a data pointer would not do -- the caching allocator recycles addresses)."""
     if attention_mask is None:
         return None, None
-    if _RANGE_CACHE.get("mask") is attention_mask and _RANGE_CACHE.get("version") == attention_mask._version:
-        return _RANGE_CACHE["start"], _RANGE_CACHE["length"]
+    with _RANGE_LOCK:                                    # one consistent (mask, version, start, length) record per look-up
+        ref = _RANGE_CACHE.get("mask")
+        if ref is not None and ref() is attention_mask and _RANGE_CACHE.get("version") == attention_mask._version:
+            return _RANGE_CACHE["start"], _RANGE_CACHE["length"]
     start, length = _token_ranges(attention_mask)
-    _RANGE_CACHE.update(mask=attention_mask, version=attention_mask._version, start=start, length=length)
+    with _RANGE_LOCK:                                    # weak reference: the cache does not keep the last mask alive
+        _RANGE_CACHE.update(mask=weakref.ref(attention_mask), version=attention_mask._version, start=start, length=length)
     return start, length
 
 

@@ -50,5 +50,11 @@ def test_hand_scheduled_kernels_do_not_spill(which, tmp_path):
     for n in watched:
         if "attn32_kernel" in n or "prefill32_kernel" in n:
             assert kernels[n]["private_segment_fixed_size"] == 0 and kernels[n]["vgpr_spill_count"] == 0, (n, kernels[n])
+    # round 4's persistent GEMMs count every VMEM request by hand AND use all 256 accumulator registers: any spill is a bug
+    ps = [n for n in kernels if re.search(r"gemm_ps(32)?_kernel", n)]
+    if which == "diag":
+        assert ps, "the diagnostic library lost the persistent GEMM alternatives"
+    for n in ps:
+        assert kernels[n]["private_segment_fixed_size"] == 0 and kernels[n]["vgpr_spill_count"] == 0, (n, kernels[n])
     spilled = {n: kernels[n]["vgpr_spill_count"] for n in watched if kernels[n]["vgpr_spill_count"] > 40}
     assert not spilled, f"register spills grew: {spilled}"

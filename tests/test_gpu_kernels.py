@@ -206,6 +206,45 @@ def test_gemm_direct_b_small_and_edge_shapes(dev, dtype, M, N, K, tile):
             lib.slime_gemm_force_tile(0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("tile", [16, 17])
+@pytest.mark.parametrize("M,N,epi_name", [(11540, 4096, "quick_gelu"), (11540, 3072, "bias"), (8212, 4096, "quick_gelu"), (23080, 3072, "bias")])
+def test_gemm_persistent_equals_direct_b(dev, dtype, tile, M, N, epi_name):
+    """Round 4's measured alternatives (diagnostic build; profiles/r04_ps_ablation.txt): the persistent direct-B kernels whose
+    epilogue rides in the next tile's MFMA stream -- tile 16 on 16x16x32 MFMAs (bf16 only: fp16 falls through to tile 17), tile 17
+    on 32x32x16 -- reproduce gemm_db_kernel BIT FOR BIT on the LayerNorm-fold consumers (q/k/v, fc1) at the tower's launch shapes:
+    ragged last row tile, 3-12 tiles per workgroup, every workgroup's last tile through the stand-alone drain; rows past M of
+    the output buffer stay untouched (buffer stores bounded at M rows).  Also pins tools/mfma_shape_equal.hip's finding that the
+    two MFMA shapes accumulate to the same fp32 bits."""
+    import ctypes as C
+    from slime_amd import ops, _lib
+    K = 1024
+    epi = _lib.EPI_BIAS_QUICKGELU_T if epi_name == "quick_gelu" else _lib.EPI_BIAS_T
+    x = _rand((M, K), torch.float32, dev, 1) + _rand((M, 1), torch.float32, dev, 2, 0.5)
+    x16 = x.to(dtype)
+    stats = torch.stack([x.view(M, K // 64, 64).sum(-1), (x * x).view(M, K // 64, 64).sum(-1)], dim=-1).contiguous()
+    w = _rand((N, K), dtype, dev, 3, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 4, 0.5)
+    colsum = w.float().sum(-1).contiguous()
+    wf = ops.pack_b_frag(w)
+    with _lib.diag() as lib:
+        outs = {}
+        try:
+            for t in (12, tile):
+                buf = torch.full((M + 64, N), 7.0, dtype=dtype, device=dev)
+                g = _lib.GemmArgs(A=x16.data_ptr(), lda=K, B=w.data_ptr(), bias=bias.data_ptr(), C=buf.data_ptr(), ldc=N, M=M, N=N, K=K,
+                                  dtype=ops.dtype_code(dtype), epilogue=epi, ln_stats=stats.data_ptr(), ln_groups=K // 64,
+                                  ln_colsum=colsum.data_ptr(), ln_eps=1e-5, B_frag=wf.data_ptr())
+                lib.slime_gemm_force_tile(t)
+                _lib.check(lib.slime_gemm_ex(C.byref(g), ops._stream()), "slime_gemm_ex")
+                torch.cuda.synchronize()
+                outs[t] = buf
+        finally:
+            lib.slime_gemm_force_tile(0)
+    assert bool((outs[tile][M:] == 7.0).all()), "rows past M were written"
+    assert torch.equal(outs[tile], outs[12])
+
+
 def test_gemm_direct_b_determinism_under_load(dev):
     """Counted waits: a load that is waited for too early shows up as run-to-run differences, not as a large error.  The same
     GEMM 20 times while a second stream keeps the memory system busy: every result identical."""

@@ -341,6 +341,39 @@ def test_fused_adapter_full_dims_and_errors(dev):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_adapter_bench_shape_vs_oracle(dev, dtype):
+    """the bench step's own adapter launch -- SliME-8B dims, 8 images x (1 + 4) crops, 13 824 stacked MLP rows
+    (gemm_db_kernel<.., 3, 1, 8> / <.., 2, 0, 8>), 2 x 2 merge -- against the fp32 CPU oracle as a whole: gated global rows and
+    merged local rows of every image.  Input = 40 crops of tower-like features (unit-variance tokens with a per-crop offset);
+    stated bounds: fp16 1.2e-3, bf16 8e-3 (measured 5-7e-4 / 4-6e-3)."""
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    A = W.ADAPTER_8B
+    asd = W.make_adapter_state_dict(A, seed=4321)
+    proj_sd, post_sd = W.sub_state(asd, "mm_projector."), W.sub_state(asd, "sampler.post_qformer.")
+    pg = ops.pack_gated(proj_sd, A, dtype, dev)
+    post = ops.pack_resampler(post_sd, 1024, 8, 576, dtype, dev, A.ln_eps)
+    B, n = 8, 4
+    g = torch.Generator().manual_seed(31)
+    feats32 = torch.randn(B * (1 + n), 576, 1024, generator=g) + 0.3 * torch.randn(B * (1 + n), 1, 1024, generator=g)
+    feats = feats32.to(dtype)                                            # what the tower hands over in the bench dtype
+    out = ops.adapter_forward(pg, post, feats.to(dev), B, n, 2, 2, True, -1, torch.float32).cpu()
+    assert out.shape == (B, 576 + n * 144, 4096)
+    bound = {torch.float16: 1.2e-3, torch.bfloat16: 8e-3}[dtype]
+    ref_in = feats.float()                                               # the oracle sees the same (rounded) features
+    worst = 0.0
+    for i in range(B):
+        f = ref_in[i * (1 + n):(i + 1) * (1 + n)]
+        glob = O.gated_block_forward(proj_sd, f[0], A.num_heads)
+        comp = O.resampler_forward(post_sd, f[1:], A.num_heads, A.ln_eps)
+        merged = O.spatial_merge(O.mlp_projector(proj_sd, comp), 2, 2, 12)
+        eg, el = rel_l2(out[i, :576], glob), rel_l2(out[i, 576:], merged)
+        worst = max(worst, eg, el)
+        assert eg < bound and el < bound, (i, dtype, eg, el)
+    print(f"fused adapter, bench shape, {dtype}: worst rel-L2 over 8 images {worst:.3e}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_cfg3_layout_17_crops_vs_oracle(dev, dtype):
     """BASELINE config 3's layout (1 global + 16 local crops on an explicit 4 x 4 grid -- synthetic: the reference slicer
     never emits more than 7 crops), 2 images, tiny geometry: tower + fused adapter against the oracle's stages."""

@@ -3,8 +3,11 @@ and the committed golden vectors (produced by the reference itself, oracle/make_
 
 Stated tolerances (rel-L2 vs the fp32 oracle; MFMA operands 16-bit, fp32 accumulate / residual
 stream / LayerNorm / softmax statistics):
-    fp16 operands : tower 3e-3, adapter stages 3e-3   (the reference's own fp16-vs-fp32 drift: 1.5e-3)
-    bf16 operands : tower 1.5e-2, adapter stages 1.5e-2 (the reference's own bf16-vs-fp32 drift: 1.2e-2)
+    fp16 operands : tower 1.2e-3, adapter stages 1.2e-3 (measured 5.6e-4; the reference's own fp16-vs-fp32 drift: 1.5e-3)
+    bf16 operands : tower 8e-3, adapter stages 8e-3     (measured 4.4e-3; the reference's own bf16-vs-fp32 drift: 1.2e-2)
+    projector outputs at the end of the chain (tower + adapter): fp16 1e-3 (north_star's target), bf16 1.2e-2 (measured 6.3e-3)
+Round 4: the bounds sit at ~2x what the kernels deliver instead of 3-5x, so a regression that doubles an error
+fails here.
 """
 import os
 
@@ -16,7 +19,7 @@ from conftest import GOLDEN, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float16: 3e-3, torch.bfloat16: 1.5e-2}
+TOL = {torch.float16: 1.2e-3, torch.bfloat16: 8e-3}
 
 
 @pytest.fixture(scope="module")
@@ -224,7 +227,7 @@ def test_projector_outputs_within_north_star_tolerance(dev, full20, record_prope
         g_ref = O.gated_block_forward(proj_sd, ref_feats[0], A.num_heads)
         comp = O.resampler_forward(post_sd, ref_feats[1:n], A.num_heads, A.ln_eps)
         refs[name] = (g_ref, O.spatial_merge(O.mlp_projector(proj_sd, comp), nw, nh, 12))
-    for dtype, bound in ((torch.float16, 1e-3), (torch.bfloat16, 3e-2)):
+    for dtype, bound in ((torch.float16, 1e-3), (torch.bfloat16, 1.2e-2)):
         pt = ops.pack_tower(tsd, W.CLIP_L_336, dtype, dev)
         pg = ops.pack_gated(proj_sd, A, dtype, dev)
         post = ops.pack_resampler(post_sd, 1024, 8, 576, dtype, dev, A.ln_eps)

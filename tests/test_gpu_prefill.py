@@ -82,8 +82,12 @@ def test_prepare_inputs_labels_for_multimodal_end_to_end(dev):
     # out-of-bounds device read
     bad = ids.clone()
     bad[0, 5] = 10 ** 6
-    with pytest.raises(IndexError, match="vocabulary"):
+    with pytest.raises(IndexError, match="index out of range"):
         enc.prepare_inputs_labels_for_multimodal(bad.to(dev), None, am_d, None, lab_d, px, image_sizes=sizes)
+    neg = ids.clone()
+    neg[0, 5] = -7                                  # a negative id other than IMAGE_TOKEN_INDEX would be read as an image-feature row
+    with pytest.raises(IndexError, match="index out of range"):
+        enc.prepare_inputs_labels_for_multimodal(neg.to(dev), None, am_d, None, lab_d, px, image_sizes=sizes)
 
 
 # ------------------------------------------------------------------------------------------------ RoPE / attention
@@ -428,26 +432,74 @@ def test_llama_attention_position_ids_broadcast(dev, form):
     # the patched HF module (llama_flash_attn_monkey_patch.py:105-115 counterpart)
     from transformers.models.llama import modeling_llama as M
     from transformers import LlamaConfig
-    from slime_amd.model.language_model.llama_attention import replace_llama_attn_with_hip_attn
+    from slime_amd.model.language_model.llama_attention import replace_llama_attn_with_hip_attn, restore_llama_attn, _self_attn_return_arity
     orig = M.LlamaAttention.forward
     try:
         replace_llama_attn_with_hip_attn()
+        assert len(M.LlamaAttention.forward(M.LlamaAttention(LlamaConfig(hidden_size=D, num_attention_heads=HQ, num_key_value_heads=HKV,
+                   head_dim=128, intermediate_size=256, num_hidden_layers=1, vocab_size=64), layer_idx=0).to(dev), hidden)) == _self_attn_return_arity(M)
         cfg = LlamaConfig(hidden_size=D, num_attention_heads=HQ, num_key_value_heads=HKV, head_dim=128, intermediate_size=256,
                           num_hidden_layers=1, rope_theta=500000.0, vocab_size=64)
         att = M.LlamaAttention(cfg, layer_idx=0)
         att.load_state_dict({k: v for k, v in m.state_dict().items()}, strict=False)
         att.to(dev)
-        got2, _, _ = att(hidden, attention_mask=None, position_ids=pid)
+        got2 = att(hidden, attention_mask=None, position_ids=pid)[0]
         assert torch.equal(got2, want)
         # stale-cache guard: an in-place weight edit after the first forward must be seen
         with torch.no_grad():
             att.o_proj.weight.mul_(2.0)
-        got3, _, _ = att(hidden, attention_mask=None, position_ids=pid)
+        got3 = att(hidden, attention_mask=None, position_ids=pid)[0]
         assert rel_l2(got3.float().cpu(), (2.0 * want).float().cpu()) < 2e-2 and not torch.equal(got3, got2)
         with pytest.raises(NotImplementedError, match="use_cache=False"):
             att(hidden, attention_mask=None, position_ids=pid, use_cache=True)
     finally:
-        M.LlamaAttention.forward = orig
+        restore_llama_attn()
+        assert M.LlamaAttention.forward is orig
+
+
+@pytest.mark.parametrize("padding", ["right", "left", "none"])
+def test_patched_attention_inside_hf_llama_model(dev, padding):
+    """VERDICT r3 missing #4: ``replace_llama_attn_with_hip_attn`` (counterpart of llama_flash_attn_monkey_patch.py:105-115) inside a
+    REAL HF decoder stack of the installed transformers -- a 2-layer random-init ``LlamaModel(inputs_embeds=..., attention_mask=...)``
+    with the patch (bf16, on the GPU) against the stock fp32 CPU forward (eager attention, HF's own 4-D causal + padding mask).
+    Exercises what broke under transformers >= 4.48: the 2-value return ``LlamaDecoderLayer`` unpacks, ``position_embeddings`` /
+    ``position_ids`` keywords, and the model-level mask builder handing the [B, S] key-padding mask through un-expanded."""
+    from transformers.models.llama import modeling_llama as M
+    from transformers import LlamaConfig
+    from slime_amd.model.language_model.llama_attention import replace_llama_attn_with_hip_attn, restore_llama_attn
+    torch.manual_seed(3)
+    cfg = LlamaConfig(hidden_size=512, num_attention_heads=4, num_key_value_heads=2, head_dim=128, intermediate_size=1024,
+                      num_hidden_layers=2, rope_theta=500000.0, vocab_size=128, attn_implementation="eager")
+    ref_model = M.LlamaModel(cfg).eval()
+    B, S = 3, 83
+    emb = torch.randn(B, S, 512) * 0.5
+    lens = [83, 61, 17]
+    mask = torch.zeros(B, S, dtype=torch.long)
+    for b, n in enumerate(lens):
+        if padding == "left":
+            mask[b, S - n:] = 1
+        else:
+            mask[b, :n] = 1
+    if padding == "none":
+        mask = None
+    with torch.no_grad():
+        ref = ref_model(inputs_embeds=emb, attention_mask=mask, use_cache=False).last_hidden_state
+    import copy
+    gpu_model = copy.deepcopy(ref_model).to(dev).to(torch.bfloat16)
+    orig = M.LlamaAttention.forward
+    try:
+        replace_llama_attn_with_hip_attn()
+        with torch.no_grad():
+            got = gpu_model(inputs_embeds=emb.to(dev).to(torch.bfloat16), attention_mask=None if mask is None else mask.to(dev),
+                            use_cache=False).last_hidden_state
+    finally:
+        restore_llama_attn()
+    assert M.LlamaAttention.forward is orig
+    got = got.float().cpu()
+    valid = torch.ones(B, S, dtype=torch.bool) if mask is None else mask.bool()
+    err = rel_l2(got[valid], ref[valid])
+    print(f"patched LlamaModel ({padding} padding) vs stock fp32 CPU forward: rel-L2 {err:.3e}")
+    assert torch.isfinite(got).all() and err < 2.5e-2                    # bf16 stack (HF's own RMSNorm / MLP in bf16 included)
 
 
 def test_splice_out_of_range_sources(dev):
