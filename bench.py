@@ -303,7 +303,8 @@ def main():
         lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
 
         per_rank_crops = -(-n_step // world)
-        chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world)}.get(args.gather, 0)
+        chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world, device_name=torch.cuda.get_device_name(dev),
+                                                      model="CLIP-ViT-L/14-336", dtype="bf16")}.get(args.gather, 0)
 
         def tower_fn(x):
             return vm.encode(x, -2, False, dt)

@@ -12,7 +12,9 @@ single-GPU result.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+import json
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -33,26 +35,69 @@ def image_shard(n_images: int, world: int, rank: int) -> List[int]:
     return list(range(lo, hi))
 
 
-# Tower latency on one MI355X, bf16, one encode() call over n crops (tools/stream_split_sweep.py, tools/rank_shapes.py;
-# profiles/r03_stream_split_sweep.txt): a pass costs ~2.4 ms however few crops it holds (23 layers x 5 dependent launches of 5-30 us
-# kernels) and ~0.33 ms per crop beyond ~16 crops, where the GEMM grids fill the chip.  From 8 crops on encode() runs two half batches
-# on two streams (the step between 7 and 8 crops is the out_proj / fc2 grid crossing one workgroup per CU).  (Measured before the round's last
-# kernel change -- attention K/V requests three granules ahead, 1.2 us per launch at 5 crops, 7-8 us at 20 -- i.e. 1-2 % pessimistic now.)
-TOWER_MS = {1: 2.40, 2: 2.55, 3: 2.75, 4: 2.93, 5: 3.15, 6: 3.31, 7: 3.56, 8: 4.38, 9: 4.45, 10: 4.74, 12: 5.39, 14: 5.94, 16: 6.77,
-            17: 7.05, 20: 8.11, 24: 9.32, 28: 10.54, 34: 13.21, 40: 15.22}
+# Tower latency curve the exchange policy decides from.  It is DATA, not code: a profile of one (device, model, dtype) --
+# slime_amd/data/tower_latency_mi355x_vitl336_bf16.json by default, SLIME_TOWER_LATENCY_JSON for another file, or
+# ``calibrate_tower_latency`` to measure the running configuration once.  On MI355X / ViT-L-336 / bf16: a pass costs ~2.4 ms however
+# few crops it holds (23 layers x 5 dependent launches of 5-30 us kernels) and ~0.33 ms per crop beyond ~16 crops, where the GEMM
+# grids fill the chip; from 8 crops on encode() runs two half batches on two streams.
+_DEFAULT_PROFILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tower_latency_mi355x_vitl336_bf16.json")
+_profile_cache: Dict[str, dict] = {}
 
 
-def tower_ms(n: int) -> float:
-    """Measured tower latency for n crops (piece-wise linear through TOWER_MS; 0.334 ms per crop past the table)."""
+def tower_latency_profile(path: Optional[str] = None) -> dict:
+    """The latency profile: {"device", "model", "dtype", "ms": {n: ms}, "ms_per_crop_beyond"}."""
+    path = path or os.environ.get("SLIME_TOWER_LATENCY_JSON") or _DEFAULT_PROFILE
+    if path not in _profile_cache:
+        with open(path) as f:
+            prof = json.load(f)
+        prof["ms"] = {int(k): float(v) for k, v in prof["ms"].items()}
+        _profile_cache[path] = prof
+    return _profile_cache[path]
+
+
+def profile_applies(profile: dict, device_name: Optional[str] = None, model: Optional[str] = None, dtype: Optional[str] = None) -> bool:
+    """Does the profile describe the configuration that is running?  Unknown (None) fields are not held against it."""
+    def ok(want, have):
+        return have is None or want is None or str(want).lower().replace(" ", "") in str(have).lower().replace(" ", "") \
+            or str(have).lower().replace(" ", "") in str(want).lower().replace(" ", "")
+    return ok(profile.get("device"), device_name) and ok(profile.get("model"), model) and ok(profile.get("dtype"), dtype)
+
+
+def calibrate_tower_latency(tower_fn: Callable[[torch.Tensor], torch.Tensor], make_crops: Callable[[int], torch.Tensor],
+                            sizes: Sequence[int] = (1, 2, 3, 5, 7, 8, 9, 12, 17, 24, 34, 40), reps: int = 5) -> dict:
+    """Measure the curve on the running device / model / dtype (one-off, a few hundred ms): returns a profile dict usable as
+    ``choose_chunk(..., profile=...)`` or to be dumped as JSON for SLIME_TOWER_LATENCY_JSON."""
+    ms = {}
+    for n in sizes:
+        x = make_crops(n)
+        for _ in range(2):
+            tower_fn(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            tower_fn(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[int(n)] = e0.elapsed_time(e1) / reps
+    ks = sorted(ms)
+    slope = (ms[ks[-1]] - ms[ks[-2]]) / (ks[-1] - ks[-2]) if len(ks) > 1 else 0.0
+    return {"device": torch.cuda.get_device_name(), "model": None, "dtype": None, "ms": ms, "ms_per_crop_beyond": slope, "source": "calibrate_tower_latency"}
+
+
+def tower_ms(n: int, profile: Optional[dict] = None) -> float:
+    """Tower latency for n crops from the profile (piece-wise linear through its points, constant slope past the table)."""
     if n <= 0:
         return 0.0
-    ks = sorted(TOWER_MS)
+    prof = profile or tower_latency_profile()
+    tab = prof["ms"]
+    ks = sorted(tab)
     if n >= ks[-1]:
-        return TOWER_MS[ks[-1]] + 0.334 * (n - ks[-1])
+        return tab[ks[-1]] + float(prof.get("ms_per_crop_beyond", 0.0)) * (n - ks[-1])
     for a, b in zip(ks, ks[1:]):
         if a <= n <= b:
-            return TOWER_MS[a] + (TOWER_MS[b] - TOWER_MS[a]) * (n - a) / (b - a)
-    return TOWER_MS[ks[0]]
+            return tab[a] + (tab[b] - tab[a]) * (n - a) / (b - a)
+    return tab[ks[0]]
 
 
 def gather_ms(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0) -> float:
@@ -64,14 +109,23 @@ def gather_ms(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, l
     return 0.03 + (world - 1) * per_rank * bytes_per_crop / (link_gb_s * 1e6)
 
 
-def choose_chunk(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0) -> int:
+def choose_chunk(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0,
+                 profile: Optional[dict] = None, device_name: Optional[str] = None, model: Optional[str] = None,
+                 dtype: Optional[str] = None) -> int:
     """Micro-batch size for ``sharded_tower`` (0 = one tower pass + one all-gather).  Chunking hides all but the last
     micro-batch's transfer under the remaining tower work but pays the tower's per-pass floor once per extra micro-batch:
-    it is chosen only where the modelled saving exceeds that cost.  With the measured curve that is never the case at the
+    it is chosen only where the modelled saving exceeds that cost -- and only when the latency profile describes the running
+    configuration (``device_name`` / ``model`` / ``dtype``; otherwise 0).  With the MI355X curve that is never the case at the
     per-rank sizes of BASELINE configs 2 / 3 / 5 (5 ... 34 crops: a second pass costs 1.8-3 ms, the whole transfer <= 0.8 ms
     -- round 2's fixed chunk of 3 turned 9 crops from 4.8 into 8.2-9.7 ms); it starts to pay at ~100 crops per rank on 8 GPUs."""
     if world <= 1 or per_rank < 2:
         return 0
+    profile = profile or tower_latency_profile()
+    if not profile_applies(profile, device_name, model, dtype):
+        return 0                                            # a curve of another device / tower / dtype decides nothing: one pass, one gather
+
+    def tower_ms(n):                                        # noqa: F811 -- the curve of THIS profile
+        return globals()["tower_ms"](n, profile)
     best, best_t = 0, tower_ms(per_rank) + gather_ms(per_rank, world, bytes_per_crop, link_gb_s)
     for k in (2, 3, 4):                                     # number of micro-batches
         c = -(-per_rank // k)

@@ -83,6 +83,9 @@ class HipCLIPVisionModel(nn.Module):
         self.vision_model = _VisionTransformer(config)
         self.compute_dtype = compute_dtype     # MFMA operand type used when the parameters are fp32
         self.two_streams = True
+        # crop count from which encode() splits the batch over two streams: 8 is the measured break-even of ViT-L/14-336 on MI355X
+        # (profiles/r03_stream_split_sweep.txt) -- another tower or device may want another value (SLIME_TOWER_SPLIT_MIN)
+        self.split_min_crops = int(os.environ.get("SLIME_TOWER_SPLIT_MIN", "8"))
         self.force_streams = 0                # tools/stream_split_sweep.py: 1 / 2 = override the split policy below
         self._packed: Dict = {}
         self._streams: Optional[List[torch.cuda.Stream]] = None
@@ -136,7 +139,7 @@ class HipCLIPVisionModel(nn.Module):
         # has the split ahead or equal at every count >= 8 (9 crops 4.79 -> 4.43 ms, 14: 6.65 -> 5.91, 40: 16.5 -> 15.1) and behind
         # below (7 crops 3.49 vs 4.01: two passes of the 2.4 ms floor); rounds 1-2 measured 14-16 as the break-even with the old
         # small-grid kernels
-        split = self.two_streams and n >= 8
+        split = self.two_streams and n >= self.split_min_crops
         if self.force_streams:
             split = self.force_streams == 2 and n >= 2
         if not split:

@@ -296,10 +296,19 @@ def test_gather_chunk_cost_model():
     """slime_amd.dist.choose_chunk: one tower pass + one all-gather at every per-rank size BASELINE's configs produce (round 2's
     fixed chunk of 3 doubled a 9-crop shard's tower time); micro-batches only where the modelled transfer exceeds a second pass."""
     from slime_amd import dist as D
+    prof = D.tower_latency_profile()                                     # slime_amd/data/tower_latency_mi355x_vitl336_bf16.json
+    T = prof["ms"]
+    assert prof["device"] == "MI355X" and prof["dtype"] == "bf16" and T[1] == 2.40 and T[40] == 15.22
     for n in (1, 5, 9, 17, 34, 40, 68):
-        assert abs(D.tower_ms(n) - (D.TOWER_MS[n] if n in D.TOWER_MS else D.tower_ms(n))) < 1e-9
-    assert D.tower_ms(0) == 0.0 and D.tower_ms(11) == pytest.approx((D.TOWER_MS[10] + D.TOWER_MS[12]) / 2)
-    assert D.tower_ms(60) == pytest.approx(D.TOWER_MS[40] + 0.334 * 20)
+        assert abs(D.tower_ms(n) - (T[n] if n in T else D.tower_ms(n))) < 1e-9
+    assert D.tower_ms(0) == 0.0 and D.tower_ms(11) == pytest.approx((T[10] + T[12]) / 2)
+    assert D.tower_ms(60) == pytest.approx(T[40] + 0.334 * 20)
+    # ADVICE r3: the curve is a profile of ONE device / tower / dtype; for anything else the policy decides nothing (chunk 0)
+    assert D.profile_applies(prof, "AMD Instinct MI355X", "CLIP-ViT-L/14-336", "bf16") and D.profile_applies(prof)
+    assert not D.profile_applies(prof, "AMD Instinct MI300X") and not D.profile_applies(prof, None, None, "fp16")
+    assert D.choose_chunk(400, 8) > 0 and D.choose_chunk(400, 8, device_name="AMD Instinct MI300X") == 0
+    flat = {"device": "MI355X", "model": None, "dtype": None, "ms": {1: 0.1, 100: 10.0}, "ms_per_crop_beyond": 0.1}
+    assert D.choose_chunk(34, 8, profile=flat) > 0                        # no per-pass floor in this curve: micro-batches pay early
     assert all(D.tower_ms(a) <= D.tower_ms(b) for a, b in zip(range(1, 80), range(2, 81)))          # monotone
     assert D.gather_ms(9, 1) == 0.0 and D.gather_ms(9, 8) == pytest.approx(0.03 + 7 * 9 * 576 * 1024 * 2 / 100e6)
     for per, world in ((40, 1), (20, 2), (10, 4), (5, 8), (34, 2), (17, 4), (9, 8), (1, 8)):
