@@ -180,9 +180,20 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                     v[4 + j] = fmaf(rn[i].x, acc[i][2 * p + 1][j], fmaf(rn[i].y, cs[p][4 + j], bias[p][4 + j]));
                 }
                 if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
+                    // x sigmoid(1.702 x) on PAIRS: the multiply by C, the 1 + e and the final product as v_pk_mul / v_pk_add (two
+                    // elements per issue; hipcc packs the first multiply on its own but leaves the other two scalar behind the
+                    // scalar v_exp / v_rcp).  Same IEEE operations per element: results unchanged (round 4).
                     constexpr float C = -1.702f * 1.4426950408889634f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(C * v[j]));
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2 z = {v[j], v[j + 1]};
+                        const f32x2 u = z * C;
+                        f32x2 e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+                        e = e + 1.0f;
+                        const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                        const f32x2 y = z * r;
+                        v[j] = y[0]; v[j + 1] = y[1];
+                    }
                 }
                 const u32x4 w = pack8<T>(v);
                 if (in_range(row))
