@@ -51,6 +51,9 @@ GF_VIT_PER_CROP = 366.034              # live ViT path, 23 layer
 GF_GLOBAL_PER_IMAGE = 54.512           # gated adapter on the global view
 GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# What the matrix pipes deliver on THIS chip with fresh random bf16 operands in every MFMA and nothing else in the stream (the chip
+# clocks to its 1400 W cap: profiles/r04_ps_ablation.txt, profiles/r04_power_cap.txt).  Reported beside `peak`, never instead of it.
+MFMA_STREAM_AT_POWER_CAP_TFLOPS = 1616.0
 PMC_FILE = "r04_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
 
 CONFIGS = {                            # images per step, local crops per image, local grid
@@ -417,7 +420,11 @@ def main():
                        "step_pipelining": "none" if tail_stream is None else "gather+adapter of step i on a second stream, under the tower of step i+1",
                        **extra_cfg},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
-                          "gflop_per_step": round(step_gf, 1)},
+                          "gflop_per_step": round(step_gf, 1),
+                          "power_capped_mfma_stream_tflops": MFMA_STREAM_AT_POWER_CAP_TFLOPS,
+                          "frac_of_power_capped_mfma_stream": round(path_tflops / (MFMA_STREAM_AT_POWER_CAP_TFLOPS * world), 4),
+                          "power_note": "the step runs at the 1400 W cap (sclk 1.96 of 2.40 GHz; 13.0 instead of 15.0 ms on all-zero operands): "
+                                        "profiles/r04_power_cap.txt; the bare MFMA stream on fresh random operands reaches 1616 TF/s here: profiles/r04_ps_ablation.txt"},
             "roofline": {"bound": "mfma",
                          "kernel": f"{roof_kernel['rocprof_name']} ({roof_kernel['label']}, M={roof_kernel['M']} N={roof_kernel['N']} K={roof_kernel['K']})",
                          "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",

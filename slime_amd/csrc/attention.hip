@@ -30,6 +30,7 @@ struct AttnArgs {
     unsigned long long* dbg;      // diagnostic: 4 s_memtime stamps per wave (NULL in production)
     int abl;                      // diagnostic timing ablations of attn64 (0 in production): 1 = no softmax VALU, 2 = no MFMA
     int n_full = 0, split = 1, n_cut = 0;   // attn32: items (crop, head) < n_full are one workgroup each, the n_cut others `split` each
+    int n_items = 0;              // attn64g: heads x batch (its grid is one-dimensional)
 };
 
 template <int DH> __device__ __forceinline__ int v_swizzle(int row) {
@@ -598,16 +599,21 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
 // 80 KiB, and the rest of the panel streams in under the arithmetic -- three granules ahead of their use (round 3; requesting
 // the whole panel at once made every workgroup's first granule queue behind everybody else's panels).
 // ================================================================================================
-template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3>
+// RING (rows, a power of two; 0 = the resident 608-row panel): K and V live in a ring of RING rows each -- granule gi sits in slot
+// gi mod (RING / 8 NW) -- so a workgroup needs 2 x RING x 128 bytes of LDS instead of 152 KiB (attn64g_kernel below).
+template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3, int RING = 0>
 __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0,
                                              unsigned long long* t_first = nullptr) {    // diagnostic: when the first granule was ready
     constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608;
+    static_assert(RING == 0 || (!RESIDENT && !KPF && (RING & (RING - 1)) == 0 && RING % (8 * NW) == 0 && RING / (8 * NW) >= AHEAD + 3),
+                  "ring: streaming pass only; a slot is re-filled three granules after its last reader (see granule_ready)");
+    constexpr unsigned RMASK = RING ? RING * RB - 1 : 0xffffffffu;
     constexpr int NG = (KC / 8 + NW - 1) / NW;            // DMA granules of NW pieces = 8 NW rows (8 waves: 10 x 64 rows, 12 waves: 7 x 96 rows;
                                                            // the last one holds 4 real pieces, rows 576..607)
     constexpr int SPG = NW / 4;                            // 32-row kv steps per granule
     constexpr float RESCALE_TH = 8.0f;
     char* Klds = smem;
-    char* Vlds = smem + KC * RB;
+    char* Vlds = smem + (RING ? RING : KC) * RB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -624,10 +630,11 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
         int piece = gi * NW + wave;
         if (piece >= KC / 8) piece = KC / 8 - 4 + (wave & 3);
         const int row = min(piece * 8 + lrow, a.n_kv - 1);
+        const int slot = RING ? piece % (RING / 8) : piece;
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(kbase + ((size_t)row * a.k_rs) * 2 + kchunk * 16),
-                                         LDS_PTR(Klds + piece * 1024), 16, 0, 0);
+                                         LDS_PTR(Klds + slot * 1024), 16, 0, 0);
         __builtin_amdgcn_global_load_lds(GLOBAL_PTR(vbase + ((size_t)row * a.v_rs) * 2 + vchunk * 16),
-                                         LDS_PTR(Vlds + piece * 1024), 16, 0, 0);
+                                         LDS_PTR(Vlds + slot * 1024), 16, 0, 0);
     };
     u32x4 qf[NSUB > 0 ? NSUB : 1][KS];
     const char* qbase = a.q + ((size_t)b * a.q_bs + (size_t)h * DH) * 2;
@@ -673,6 +680,10 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
     // spent 31 % of its life waiting for its FIRST granule -- behind the up-to-152 KiB the other CUs of its XCD had queued each;
     // with 3 ahead the queues are shallow: start-up 13.4 k -> 7.3 k ticks, the steps themselves 6 % faster, kernel 61.4 -> 53.2 us
     // at 20 crops, 105 -> 94 at 40, 18.6 -> 17.4 at 5; bit-equal (same arithmetic, same LDS layout).  2 ahead measures the same.
+    // RING: granule gi + AHEAD goes into the slot of granule gi + AHEAD - RING / (8 NW).  A wave that has passed the barrier of
+    // granule gi has finished the K reads of every step before granule gi - 1 and the V reads before granule gi - 2 (qk of step
+    // st + 1 and softmax_pv of step st follow before_step(st + 2)), and the barrier extends that to every wave: granules <= gi - 3
+    // are dead, hence ring slots >= AHEAD + 3.
     auto granule_ready = [&](int gi) {
         if constexpr (!RESIDENT) {
             const int fly = min(AHEAD - 1, NG - 1 - gi);        // granules still allowed in flight
@@ -730,13 +741,17 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
         // instead of in front of the first QK MFMA.  Neutral on the clock (58.3 vs 58.1 us per 20 crops) at +16 live VGPRs,
         // like the 12-wave variant below: the kernel is not bound by exposed LDS latency.
         u32x4 kf[2][KS];
+        unsigned kring = 0, vring = 0;                        // RING: byte offset of the current 32-row step inside the ring (wave-uniform)
         auto k_request = [&]() {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = t == 0 ? lds_b128_asm<0>(kptr[ks]) : lds_b128_asm<16 * RB>(kptr[ks]);
+                for (int ks = 0; ks < KS; ++ks) kf[t][ks] = t == 0 ? lds_b128_asm<0>(kptr[ks] + kring) : lds_b128_asm<16 * RB>(kptr[ks] + kring);
+            if constexpr (RING) kring = (kring + 32 * RB) & RMASK;
+            else {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
+                for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
+            }
         };
         auto qk = [&](f32x4 (&sc)[NSUB][2], bool request_next) {
             if constexpr (!KPF) k_request();                  // register-lean form: fetch at the point of use
@@ -757,10 +772,11 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             u32x2 v0[DT], v1[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1]) : lds_tr16_asm<0>(vptr[dt >> 1]);
-                v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1]) : lds_tr16_asm<16 * RB>(vptr[dt >> 1]);
+                v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1] + vring) : lds_tr16_asm<0>(vptr[dt >> 1] + vring);
+                v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1] + vring) : lds_tr16_asm<16 * RB>(vptr[dt >> 1] + vring);
             }
-            vptr[0] += 32 * RB; vptr[1] += 32 * RB;
+            if constexpr (RING) vring = (vring + 32 * RB) & RMASK;
+            else { vptr[0] += 32 * RB; vptr[1] += 32 * RB; }
             if (masked) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -962,6 +978,62 @@ static int launch_attn64w(const AttnArgs& a0, int batch, hipStream_t stream) {
     return SLIME_OK;
 }
 
+#ifdef SLIME_DIAG
+// ================================================================================================
+// attn64g_kernel (round 4, measured alternative): the same pass on a K/V RING -- four waves, 2 x 32 KiB of LDS, <= 256 registers --
+// so that an attention workgroup no longer monopolises its CU (attn64r: 152 KiB + 8 waves x 245 registers) but can share it with
+// another attention workgroup or with a direct-B GEMM workgroup of the tower's other stream (4 waves x 256 registers, 33 KiB):
+// VALU / LDS-heavy softmax waves beside MFMA / L2-bound GEMM waves.  12 query sub-blocks per workgroup (3 per wave), i.e. four
+// workgroups per CLIP (crop, head), each streaming the whole K/V once through the ring (granule = 32 rows = one step, 8 slots,
+// 4 ahead).  One-dimensional grid: the four workgroups of an item are 8 apart in launch order -- same XCD, same L2 -- and items
+// of 8 consecutive heads fill the 8 XCDs.  Same arithmetic in the same order per query sub-block: bit-identical to attn64r.
+// Measured (tools/attn_ring_ab.py, profiles/r04_attention_ring.txt): stand-alone 52 -> 46-48 us at 20 crops, 87 -> 81-83 at 40,
+// 16 -> 13.4 at one crop, equal at 5-9; the two-stream tower 15.28-15.34 -> 15.51-15.52 ms (SLOWER), one stream equal.  Like attn32
+// in rounds 2-3: under the power cap a faster attention that does the same work moves the step nowhere.  Diagnostic build only.
+// ================================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256, 2) attn64g_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = 4, AHEAD = 4, RING = 256;
+    const int qsplit = a.sb_per_wg >> 16, sb_per_wg = a.sb_per_wg & 0xffff;
+    // launch index -> (item, split): id = 8 qsplit (item / 8) + 8 split + item % 8
+    const int id = blockIdx.x, grp = id / (8 * qsplit), rem = id % (8 * qsplit);
+    const int item = grp * 8 + (rem & 7), split = rem >> 3;
+    if (item >= a.n_items) return;                            // the grid is padded to whole groups of 8 items
+    const int h = item % a.heads, b = item / a.heads;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total_sb = (a.n_q + 15) >> 4;
+    const int wg_sb0 = split * sb_per_wg;
+    const int nsb = max(0, min(sb_per_wg, total_sb - wg_sb0));     // <= 3 * NW
+    const int base = nsb / NW, rm = nsb % NW;
+    const int cnt = base + (wave < rm ? 1 : 0);
+    const int sb0 = wg_sb0 + wave * base + min(wave, rm);
+    switch (cnt) {
+        case 0: attn64r_pass<T, 0, false, NW, false, AHEAD, RING>(a, smem, b, h, sb0); break;
+        case 1: attn64r_pass<T, 1, false, NW, false, AHEAD, RING>(a, smem, b, h, sb0); break;
+        case 2: attn64r_pass<T, 2, false, NW, false, AHEAD, RING>(a, smem, b, h, sb0); break;
+        default: attn64r_pass<T, 3, false, NW, false, AHEAD, RING>(a, smem, b, h, sb0); break;
+    }
+}
+
+template <typename T>
+static int launch_attn64g(const AttnArgs& a0, int batch, hipStream_t stream) {
+    AttnArgs a = a0;
+    constexpr int LDS = 2 * 256 * 128;
+    auto kern = attn64g_kernel<T>;
+    SLIME_SET_LDS_ONCE(kern, LDS, "attention");
+    const int total_sb = (a.n_q + 15) / 16;
+    const int qsplit = (total_sb + 11) / 12;                  // <= 3 sub-blocks per wave, 4 waves
+    const int per = (total_sb + qsplit - 1) / qsplit;
+    a.sb_per_wg = (qsplit << 16) | per;
+    a.n_items = a.heads * batch;
+    const int groups = (a.n_items + 7) / 8;
+    hipLaunchKernelGGL(kern, dim3(groups * 8 * qsplit), dim3(256), LDS, stream, a);
+    SLIME_CHECK_LAUNCH("attention64g");
+    return SLIME_OK;
+}
+#endif  // SLIME_DIAG
+
 template <typename T, int AHEAD = 3>
 static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
@@ -1059,6 +1131,10 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 7 && !g_attn_dbg) {    // round 2's product kernel, for A/B
         if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
         return launch_attn64r<BF16>(a, batch, s);
+    }
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 30 && !g_attn_dbg) {   // round 4: K/V ring, four waves, two per CU
+        if (dtype == SLIME_F16) return launch_attn64g<F16>(a, batch, s);
+        return launch_attn64g<BF16>(a, batch, s);
     }
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 3 && !g_attn_dbg) {
         if (dtype == SLIME_F16) return launch_attn64w<F16>(a, batch, s);

@@ -535,6 +535,36 @@ def test_attention32_launch_forms(dev, B, heads, nq, nkv, gain):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,heads,nq,nkv,gain", [
+    (2, 16, 577, 577, 1.0),     # CLIP geometry: 37 query sub-blocks -> four workgroups of 10 / 10 / 10 / 7 per (crop, head)
+    (3, 4, 577, 577, 12.0),     # logits with std 12: the reference maximum moves often
+    (1, 1, 577, 321, 1.0),      # shortest panel (11 steps: the ring wraps once), one item = a padded group of eight
+    (2, 3, 100, 400, 1.0),      # 7 sub-blocks: one workgroup, waves with 2 / 2 / 2 / 1
+    (2, 2, 33, 608, 2.0),       # 3 sub-blocks: an idle wave that only streams and takes part in the barriers; full panel
+    (5, 16, 577, 577, 1.0),     # 80 items
+])
+def test_attention_ring_alternative(dev, dtype, B, heads, nq, nkv, gain):
+    """Round 4's measured alternative (diagnostic variant 30, attn64g_kernel): K/V through a 2 x 32 KiB ring, four waves, two
+    workgroups per CU.  Same arithmetic in the same order per query sub-block: BIT-EQUAL to the product kernel on every shape
+    (and 6-12 % faster stand-alone at 20-40 crops; in the two-stream tower it is 1.3 % slower, profiles/r04_attention_ring.txt)."""
+    from slime_amd import ops, _lib
+    E = heads * 64
+    qkv = _rand((B, max(nq, nkv), 3 * E), dtype, dev, 51)
+    qkv[..., :E] *= gain * 0.125 * LOG2E
+    q, k, v = qkv[:, :nq, :E], qkv[:, :nkv, E:2 * E], qkv[:, :nkv, 2 * E:]
+    want = ops.attention(q, k, v, heads, 64)
+    with _lib.diag() as lib:
+        try:
+            lib.slime_attention_set_variant(30)
+            got = ops.attention(q, k, v, heads, 64)
+            torch.cuda.synchronize()
+        finally:
+            lib.slime_attention_set_variant(0)
+    assert torch.equal(got, want)
+    assert rel_l2(got.float().cpu(), _attn_ref(q, k, v, heads, 64).cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("gain", [4.0, 12.0])
 def test_attention_large_logits(dev, dtype, gain):
     """Logits with std 4 / 12: the reference max of the lazy-rescale softmax is refreshed many times,
