@@ -46,6 +46,45 @@ def measure(tag, fn, secs=4.0):
     print(f"{tag:34s}: {ms:6.2f} ms per 40 crops; rocm-smi (sclk, power): {acc[1:-1][:8]}", flush=True)
 
 
+if "--mfma" in sys.argv:
+    # the bare MFMA stream of profiles/r04_ps_ablation.txt (gemm_ps32_kernel with every memory instruction removed: diagnostic
+    # ablation 134; fc1 shape, M = 23080) and the complete persistent kernel, on random and on zero operands: is 1.62 PF a POWER limit?
+    import ctypes as C
+    from slime_amd import _lib
+    lib = _lib.load_diag(); E = _lib
+    M, N, K = 23080, 4096, 1024
+    for tag, zero in (("random operands", False), ("zero operands", True)):
+        g0 = torch.Generator().manual_seed(1)
+        x = (torch.zeros(M, K) if zero else torch.randn(M, K, generator=g0)).to(dt).to(dev)
+        w = (torch.zeros(N, K) if zero else torch.randn(N, K, generator=g0) * K ** -0.5).to(dt).to(dev)
+        stats = torch.stack([x.float().view(M, K // 64, 64).sum(-1), (x.float() ** 2).view(M, K // 64, 64).sum(-1)], -1).contiguous()
+        bias = torch.zeros(N, device=dev); colsum = w.float().sum(-1).contiguous(); wf = ops.pack_b_frag(w)
+        out = torch.empty((M, N), dtype=dt, device=dev)
+        g = E.GemmArgs(A=x.data_ptr(), lda=K, B=w.data_ptr(), bias=bias.data_ptr(), C=out.data_ptr(), ldc=N, M=M, N=N, K=K, dtype=ops.dtype_code(dt),
+                       epilogue=E.EPI_BIAS_QUICKGELU_T, ln_stats=stats.data_ptr(), ln_groups=16, ln_colsum=colsum.data_ptr(), ln_eps=1e-5, B_frag=wf.data_ptr())
+        st = ops._stream()
+        ladder = ((134, "bare MFMA stream"), (70, "+ activation-fragment reads (LDS)"), (54, "+ weight requests (L2 -> VGPR)"), (38, "+ LDS-DMA instead (L2 -> LDS)"),
+                  (22, "+ both = complete main loop"), (18, "+ counted waits"), (0, "complete persistent kernel"), (-1, "shipped direct-B kernel"))
+        for abl, name in (ladder if "--ladder" in sys.argv else (ladder[0], ladder[-2], ladder[-1])):
+            lib.slime_gemm_force_tile(12 if abl < 0 else 17); lib.slime_gemm_set_db_ablation(max(abl, 0))
+            fn = lambda: lib.slime_gemm_ex(C.byref(g), st)
+            for _ in range(5): fn()
+            torch.cuda.synchronize()
+            acc, stop = [], threading.Event(); th = threading.Thread(target=sample, args=("", stop, acc)); th.start()
+            t0 = time.time(); n = 0
+            while time.time() - t0 < 3.0:
+                for _ in range(50): fn()
+                torch.cuda.synchronize(); n += 50
+            us = (time.time() - t0) / n * 1e6
+            stop.set(); th.join()
+            ws = [float(p_) for _, p_ in acc[1:-1] if p_.replace(".", "").isdigit()]
+            w_avg = sum(ws) / max(len(ws), 1)
+            print(f"{name:36s} {tag:16s}: {us:6.1f} us = {2.0*M*N*K/us/1e6:6.0f} TF/s; {w_avg:6.0f} W -> {w_avg*us*1e-3:6.1f} mJ per launch; sclk {acc[2][0] if len(acc) > 2 else '?'}", flush=True)
+        lib.slime_gemm_force_tile(0); lib.slime_gemm_set_db_ablation(0)
+    sys.exit(0)
+
+acc0 = []; stop0 = threading.Event(); th0 = threading.Thread(target=sample, args=("", stop0, acc0)); th0.start(); time.sleep(2.0); stop0.set(); th0.join()
+print("idle (context created, nothing running): rocm-smi (sclk, W):", acc0[:4], flush=True)
 tsd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)
 px = W.synthetic_pixels(40, seed=0).to(dev).to(dt)
 zsd = {k: torch.zeros_like(v) for k, v in tsd.items()}
