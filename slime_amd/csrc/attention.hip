@@ -470,7 +470,6 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
             // first step.  Refreshing rescales the accumulators, moves cinit, and re-bases the scores that are
             // already in registers (this step's and, double buffered, the next step's).
             float mc[NSUB];
-            bool need = false;
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
@@ -478,11 +477,13 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
                 mx = __builtin_fmaxf(mx, sc[s][1][3]);
                 mc[s] = mx;                                  // this lane's 8 kv rows only: enough for the test
-                need |= mx > RESCALE_TH;
             }
-            if (__builtin_amdgcn_ballot_w64(need) != 0 || st == 0) {    // wave-uniform, rare
+            // The refresh is decided PER SUB-BLOCK (round 4): a sub-block's reference moves when one of ITS OWN scores ran away, never
+            // because a wave-mate's did -- which sub-blocks share a wave depends on the launch form (one / two / four workgroups per
+            // (crop, head), chosen by batch size), and the result must not (the sharded tower reproduces the 1-GPU tensor bit for bit).
 #pragma unroll
-                for (int s = 0; s < NSUB; ++s) {
+            for (int s = 0; s < NSUB; ++s) {
+                if (__builtin_amdgcn_ballot_w64(mc[s] > RESCALE_TH) != 0 || st == 0) {    // wave-uniform, rare
                     float d = rows_allmax(mc[s]);            // excess of this step's row max over the reference
                     d = st == 0 ? d : __builtin_fmaxf(d, 0.f);
                     const float alpha = __builtin_amdgcn_exp2f(-d);
@@ -788,7 +789,6 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                     }
             }
             float mc[NSUB];
-            bool need = false;
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
@@ -796,11 +796,11 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
                 mx = __builtin_fmaxf(mx, sc[s][1][3]);
                 mc[s] = mx;
-                need |= mx > RESCALE_TH;
             }
-            if (__builtin_amdgcn_ballot_w64(need) != 0 || st == 0) {
+            // per SUB-BLOCK refresh decision (round 4): see attn64_body -- the result must not depend on which sub-blocks share a wave
 #pragma unroll
-                for (int s = 0; s < NSUB; ++s) {
+            for (int s = 0; s < NSUB; ++s) {
+                if (__builtin_amdgcn_ballot_w64(mc[s] > RESCALE_TH) != 0 || st == 0) {
                     float d = rows_allmax(mc[s]);
                     d = st == 0 ? d : __builtin_fmaxf(d, 0.f);
                     const float alpha = __builtin_amdgcn_exp2f(-d);

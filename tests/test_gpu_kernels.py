@@ -535,6 +535,27 @@ def test_attention32_launch_forms(dev, B, heads, nq, nkv, gain):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gain", [1.0, 6.0, 12.0])
+def test_attention_launch_form_invariance(dev, dtype, gain):
+    """The launcher gives a CLIP (crop, head) one workgroup or two depending on the batch size (rounds of CUs x cost), which changes
+    which query sub-blocks share a wave.  The lazily refreshed softmax reference used to be refreshed per WAVE (any sub-block of the
+    wave running away moved all of them): with logits large enough to trigger it (real checkpoints have such heads) the SAME crop
+    came out different in the last bits at different batch sizes -- found in round 4 by the ring alternative below, which groups
+    sub-blocks differently again.  Now per sub-block: 5 crops alone (two workgroups per item), the same 5 inside 10 (one) and
+    inside 20 (two) are bit-identical at every logit scale."""
+    from slime_amd import ops
+    heads, E = 16, 1024
+    qkv = _rand((20, 577, 3 * E), dtype, dev, 52)
+    qkv[..., :E] *= gain * 0.125 * LOG2E
+    outs = {}
+    for n in (5, 10, 20):
+        q, k, v = qkv[:n, :, :E], qkv[:n, :, E:2 * E], qkv[:n, :, 2 * E:]
+        outs[n] = ops.attention(q, k, v, heads, 64)
+    assert torch.equal(outs[5], outs[10][:5]) and torch.equal(outs[5], outs[20][:5]) and torch.equal(outs[10], outs[20][:10])
+    assert rel_l2(outs[5].float().cpu(), _attn_ref(qkv[:5, :, :E], qkv[:5, :, E:2 * E], qkv[:5, :, 2 * E:], heads, 64).cpu()) < 6e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,heads,nq,nkv,gain", [
     (2, 16, 577, 577, 1.0),     # CLIP geometry: 37 query sub-blocks -> four workgroups of 10 / 10 / 10 / 7 per (crop, head)
     (3, 4, 577, 577, 12.0),     # logits with std 12: the reference maximum moves often
