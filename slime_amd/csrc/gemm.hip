@@ -32,28 +32,7 @@
 //
 // Epilogues: bias -> T; bias+quick-GELU -> T; bias+erf-GELU -> T; bias -> fp32; fp32 += (residual) [+ T copy and LayerNorm partial
 // sums]; T(acc + bias + T residual).
-#include "common.h"
-#include <type_traits>
-
-struct GemmArgs {
-    const char* A; const char* B; const float* bias; void* C;
-    int lda, ldc, M, N, K;
-    int group_m;      // row tiles per L2 patch of the ping-pong kernel (0 = default 4)
-    unsigned long long* dbg;   // ABL & 8 builds only: 4 s_memtime stamps per workgroup
-    // LayerNorm folded into this GEMM (consumer side; epilogues BIAS_T / BIAS_QUICKGELU_T): A holds the UN-normalised 16-bit rows x,
-    // B = W . diag(gamma), bias = b + W beta, and the epilogue applies  rstd * (acc - mu * colsum[n]) + bias[n]  with the row
-    // statistics (mu, rstd) finalised per workgroup from the producer's per-64-column partial sums.  NULL = plain GEMM.
-    const float* ln_stats; int ln_groups; const float* ln_colsum; float ln_eps;
-    // producer side (epilogue BIAS_RESID_F32_LN): 16-bit copy of the updated residual rows and their partial sums
-    char* x16; int ldx; float* stats_out;
-    // B in MFMA-fragment order (slime_gemm_pack_b), or NULL: lets the dispatch pick gemm_db_kernel
-    const char* Bf;
-    // gemm_db_kernel timing ablations (diagnostic build; wrong results): 1 = every tile's epilogue writes rows 0..127 (the stores
-    // stay in L2: no HBM write burst), 2 = no epilogue at all
-    int db_abl;
-    // epilogue BIAS_RESID_T: 16-bit residual rows added before the rounding (may alias C)
-    const char* resid; int ldr;
-};
+#include "gemm_shared.h"
 
 // Sum over the four 16-lane rows of a wave (lanes l, l+16, l+32, l+48), result in every row: pure VALU (permlane swaps).
 __device__ __forceinline__ float rows4_allsum(float x) {
@@ -69,17 +48,6 @@ __device__ __forceinline__ float rows4_allsum(float x) {
 // partial sums (sum x, sum x^2 per 64-column group, summed here in a FIXED order: results do not depend on the tile shape
 // of either kernel).  Ordinary loads, issued before any LDS-DMA of the prologue.  var = E[x^2] - mu^2 in fp32: sound while
 // |mu| is not orders of magnitude above sigma (residual streams are not; tests/test_gpu_path.py stresses x100 outliers).
-// (sum x, sum x^2) of a K-wide row -> (rstd, -mu rstd).  One shared definition with the operations written out (no contraction left
-// to the compiler's discretion): every kernel family finalises the statistics to the same bits.
-__device__ __forceinline__ void ln_finalize(float sx, float sq, int K, float eps, float& rstd, float& nmr) {
-    const float inv = 1.0f / (float)K;
-    const float mu = __fmul_rn(sx, inv);
-    const float m2 = __fmul_rn(mu, mu);
-    const float var = fmaxf(__fmaf_rn(sq, inv, -m2), 0.f);
-    rstd = rsqrtf(var + eps);
-    nmr = __fmul_rn(-mu, rstd);
-}
-
 template <int BM, int NT>
 __device__ __forceinline__ void stage_ln_rows(const GemmArgs& g, const int m0, float* lnrow) {
     if (!g.ln_stats) return;
@@ -1033,19 +1001,6 @@ __global__ void __launch_bounds__(256) gemm_w4_kernel(GemmArgs g) {
 // VMEM order inside a k-step: D_j behind MFMA 8 j + 3, G_nj behind MFMA 8 nj + 7.
 // Epilogues, LayerNorm fold, tile order and output layout are those of the other kernels (run_epilogue<T, EPI, 8, 4>).
 // ================================================================================================
-template <int OFF>
-__device__ __forceinline__ void gload16_frag(u32x4& d, unsigned voff, const char* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void vm_wait_frag(u32x4& d) {       // the consumer side of gload16_frag: names the register, pins the order
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(d) : "n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 // VMEM requests younger than weight request G_nj -- issued TWO k-steps before its use -- at the moment MFMA group nj of the current
 // k-step starts (mi = 16-row MFMA tiles per wave: DMA piece j of the wave's mi/2 follows MFMA mi*j + mi/2 - 1, request G_nj follows
 // MFMA mi*nj + mi - 1).  ks: k-step of the tile; more: a next tile exists (both k-steps of this tile request fragments, the previous
@@ -1227,12 +1182,6 @@ __global__ void __launch_bounds__(256) pack_b_frag_kernel(const u32x4* __restric
     out[o] = B[((size_t)n * K + 32 * s + 8 * (lane >> 4)) / 8];
 }
 
-#ifdef SLIME_DIAG
-// Round 4's persistent direct-B kernels with the epilogue in the next tile's MFMA stream: bit-identical to the kernels above,
-// measured SLOWER than gemm_db_kernel (profiles/r04_ps_ablation.txt) -- kept as measured alternatives, tiles 16 / 17.
-#include "gemm_ps32.inc"
-#include "gemm_ps.inc"
-#endif
 
 #ifdef SLIME_DIAG   // measured alternatives: compiled into libslime_hip_diag.so only
 // ================================================================================================
@@ -1811,58 +1760,11 @@ static int launch_db(const GemmArgs& g, hipStream_t stream) {
 }
 
 #ifdef SLIME_DIAG
-// Persistent direct-B kernels (gemm_ps32.inc, gemm_ps.inc; diagnostic build): one workgroup per CU, LDS = 4 A stages + 2 row
-// tables + bias / colsum of the launch
-static bool ps_usable(const GemmArgs& g, int epi) {
-    const long cus = num_cus();
-    const long nblk = (long)((g.M + 127) / 128) * (g.N / 256);
-    return g.Bf && g.N % 256 == 0 && g.N <= 8192 && g.K == 1024 && g.ln_stats && g.ln_groups == 16 && g.ln_colsum &&
-           (epi == SLIME_EPI_BIAS_T || epi == SLIME_EPI_BIAS_QUICKGELU_T) && cus % 8 == 0 && nblk >= 2 * cus &&
-           (size_t)g.M * g.ldc * 2 < (1ull << 31) && (size_t)128 * g.lda * 2 < (1ull << 32);
-}
-#define PS_LAUNCH(KERN)                                                                                              \
-    do {                                                                                                             \
-        auto kern_ = KERN;                                                                                           \
-        SLIME_SET_LDS_ONCE(kern_, LDS_FIXED + 2 * 8192 * 4, "gemm_ps");                                              \
-        hipLaunchKernelGGL(kern_, dim3(num_cus()), dim3(256), LDS_FIXED + 2 * g.N * 4, stream, g);                   \
-        SLIME_CHECK_LAUNCH("gemm_ps");                                                                               \
-        return SLIME_OK;                                                                                             \
-    } while (0)
-template <typename T, int EPI>
-static int launch_ps32(const GemmArgs& g, hipStream_t stream) {
-    if constexpr (EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
-        constexpr int LDS_FIXED = 4 * 128 * 64 * 2 + 2 * 128 * 8;
-        // slime_gemm_set_db_ablation(16 + DBG): 17 = every counted wait drained; 18 / 20 / 22 / 30 = timing-only ablations
-        if constexpr (T::id == SLIME_BF16 && EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
-            if (g.db_abl == 17) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 1>));
-            if (g.db_abl == 18) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 2>));
-            if (g.db_abl == 20) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 4>));
-            if (g.db_abl == 22) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6>));
-            if (g.db_abl == 30) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 14>));
-            if (g.db_abl == 38) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16>));          // + no weight requests
-            if (g.db_abl == 54) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 32>));          // + no LDS-DMA
-            if (g.db_abl == 70) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16 + 32>));     // + neither
-            if (g.db_abl == 134) PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16, 6 + 16 + 32 + 64>)); // + no fragment reads: MFMAs + scalar bookkeeping
-        }
-        PS_LAUNCH((gemm_ps32_kernel<T, EPI, 16>));
-    } else {
-        slime_set_error("gemm_ps32: epilogue %d has no persistent form", EPI);
-        return SLIME_EINVAL;
-    }
-}
-template <typename T, int EPI>
-static int launch_ps16(const GemmArgs& g, hipStream_t stream) {
-    if constexpr ((EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T) && T::id == SLIME_BF16) {
-        constexpr int LDS_FIXED = 4 * 128 * 64 * 2 + 2 * 128 * 8;
-        if constexpr (EPI == SLIME_EPI_BIAS_QUICKGELU_T) {
-            if (g.db_abl == 18) PS_LAUNCH((gemm_ps_kernel<T, EPI, 16, 2>));
-        }
-        PS_LAUNCH((gemm_ps_kernel<T, EPI, 16>));
-    } else {
-        return launch_ps32<T, EPI>(g, stream);
-    }
-}
-#undef PS_LAUNCH
+// Round 4's persistent direct-B kernels with the epilogue in the next tile's MFMA stream (gemm_ps.hip: gemm_ps32.inc, gemm_ps.inc):
+// bit-identical to the kernels here, measured SLOWER than gemm_db_kernel (profiles/r04_ps_ablation.txt) -- measured alternatives,
+// tiles 16 / 17, in their own translation unit of the diagnostic library.
+bool slime_diag_ps_usable(const GemmArgs& g, int epi);
+int slime_diag_launch_ps(const GemmArgs& g, int dtype, int epi, int tile, hipStream_t stream);
 #endif
 
 template <typename T, int EPI>
@@ -1962,7 +1864,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
 #endif
 #ifdef SLIME_DIAG
     if (tile == 16 || tile == 17) {                                        // persistent direct-B, measured alternatives: 16 = 16x16x32 MFMAs, 17 = 32x32x16
-        if (ps_usable(g, EPI)) return tile == 16 ? launch_ps16<T, EPI>(g, stream) : launch_ps32<T, EPI>(g, stream);
+        if (slime_diag_ps_usable(g, EPI)) return slime_diag_launch_ps(g, T::id, EPI, tile, stream);
         tile = g.Bf ? 12 : 11;
     }
 #endif

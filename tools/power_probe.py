@@ -46,6 +46,40 @@ def measure(tag, fn, secs=4.0):
     print(f"{tag:34s}: {ms:6.2f} ms per 40 crops; rocm-smi (sclk, power): {acc[1:-1][:8]}", flush=True)
 
 
+if "--hbm" in sys.argv:
+    # What does a byte cost?  Streaming copies (torch's copy kernel: probe only) over buffers that live in HBM (2 x 2 GiB), in the
+    # 256 MiB memory-side cache (2 x 48 MiB) and a read-only reduction, random and zero contents: GB/s, W, and (W - idle) / (GB/s) = mJ per GB.
+    def watts(fn, secs=3.0, reps=20):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        acc, stop = [], threading.Event(); th = threading.Thread(target=sample, args=("", stop, acc)); th.start()
+        t0 = time.time(); n = 0
+        while time.time() - t0 < secs:
+            for _ in range(reps): fn()
+            torch.cuda.synchronize(); n += reps
+        dt_ = (time.time() - t0) / n
+        stop.set(); th.join()
+        ws = [float(p_) for _, p_ in acc[1:-1] if p_.replace(".", "").isdigit()]
+        return dt_, sum(ws) / max(len(ws), 1), (acc[2][0] if len(acc) > 2 else "?")
+    acc0 = []; stop0 = threading.Event(); th0 = threading.Thread(target=sample, args=("", stop0, acc0)); th0.start(); time.sleep(2.5); stop0.set(); th0.join()
+    idle = [float(p_) for _, p_ in acc0 if p_.replace(".", "").isdigit()]; idle = sum(idle) / max(len(idle), 1)
+    print(f"idle: {idle:.0f} W", flush=True)
+    for tag, nbytes in (("HBM (2 GiB -> 2 GiB)", 2 << 30), ("memory-side cache (48 MiB -> 48 MiB)", 48 << 20), ("L2-sized (2 MiB -> 2 MiB per call, 16 calls)", 2 << 20)):
+        for kind in ("random", "zero"):
+            src = (torch.randint(0, 2 ** 31 - 1, (nbytes // 4,), dtype=torch.int32, device=dev) if kind == "random" else torch.zeros(nbytes // 4, dtype=torch.int32, device=dev))
+            dst = torch.empty_like(src)
+            reps = 4 if nbytes > (1 << 30) else 200
+            fn = (lambda: dst.copy_(src))
+            t, w, sclk = watts(fn, reps=reps)
+            gbs = 2 * nbytes / t / 1e9
+            print(f"copy  {tag:46s} {kind:6s}: {gbs:7.0f} GB/s (read + write), {w:6.0f} W, sclk {sclk}: {(w - idle) / gbs * 1e3:6.1f} mJ per GB moved", flush=True)
+            fn = (lambda: src.sum())
+            t, w, sclk = watts(fn, reps=reps)
+            gbs = nbytes / t / 1e9
+            print(f"read  {tag:46s} {kind:6s}: {gbs:7.0f} GB/s,                {w:6.0f} W, sclk {sclk}: {(w - idle) / gbs * 1e3:6.1f} mJ per GB read", flush=True)
+            del src, dst
+    sys.exit(0)
+
 if "--mfma" in sys.argv:
     # the bare MFMA stream of profiles/r04_ps_ablation.txt (gemm_ps32_kernel with every memory instruction removed: diagnostic
     # ablation 134; fc1 shape, M = 23080) and the complete persistent kernel, on random and on zero operands: is 1.62 PF a POWER limit?
