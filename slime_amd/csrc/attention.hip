@@ -235,7 +235,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, char* smem, const i
                 for (int p = 0; p < DT / 2; ++p) {
                     float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
                                   o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
-                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                    st_stream(reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2), pack8<T>(v));
                 }
             }
         }
@@ -559,7 +559,7 @@ __device__ __forceinline__ void attn64_body(const AttnArgs& a, char* smem, const
                 for (int p = 0; p < DT / 2; ++p) {
                     float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
                                   o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
-                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                    st_stream(reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2), pack8<T>(v));
                 }
             }
         }
@@ -879,21 +879,35 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 for (int p = 0; p < DT / 2; ++p) {
                     float v[8] = {o[s][2 * p][0] * inv, o[s][2 * p][1] * inv, o[s][2 * p][2] * inv, o[s][2 * p][3] * inv,
                                   o[s][2 * p + 1][0] * inv, o[s][2 * p + 1][1] * inv, o[s][2 * p + 1][2] * inv, o[s][2 * p + 1][3] * inv};
-                    *reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2) = pack8<T>(v);
+                    st_stream(reinterpret_cast<u32x4*>(obase + ((size_t)qr * a.o_rs + 32 * p + 8 * g) * 2), pack8<T>(v));
                 }
             }
         }
     }
 }
 
+#ifndef SLIME_OPT_ATTN_PAIR
+#define SLIME_OPT_ATTN_PAIR 1
+#endif
 template <typename T, int AHEAD = 3>
 __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 8, P1 = 3 * NW;                        // pass 1: <= 3 sub-blocks per wave
-    const int h = blockIdx.x, b = blockIdx.y;
+    int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+#if SLIME_OPT_ATTN_PAIR
+    // Two workgroups share a (crop, head) when the query blocks are split: both stage the same K/V panel.  The launch order deals
+    // workgroup L to XCD L & 7 (each XCD has its own L2), and in grid order the partners are heads x crops apart -- the second one
+    // fetched the panel across the fabric again (117 MB read per launch against 71 MB of q/k/v, profiles/r04_pmc_kernels.json).
+    // Re-deal: partners are L and L + 8, neighbours in time on the same XCD.
+    if (gridDim.z > 1 && ((gridDim.x * gridDim.y) & 7) == 0) {
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int j = L >> 3, p = (j / (int)gridDim.z) * 8 + (L & 7);
+        z = j % (int)gridDim.z; h = p % (int)gridDim.x; b = p / (int)gridDim.x;
+    }
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int total_sb = (a.n_q + 15) >> 4;
-    const int wg_sb0 = blockIdx.z * a.sb_per_wg;
+    const int wg_sb0 = z * a.sb_per_wg;
     const int nsb = min(a.sb_per_wg, total_sb - wg_sb0);      // <= 5 * NW
     const int n1 = min(nsb, P1), n2 = nsb - n1;               // pass 2: <= 2 per wave
 #ifdef SLIME_DIAG

@@ -99,6 +99,31 @@ __device__ __forceinline__ u32x4 pack8(const float* v) {
     return r;
 }
 
+// Measured alternative (round 4, profiles/r04_fabric_traffic.txt), OFF: results leaving with the non-temporal hint (stream / evict
+// first) and read-once inputs (the fp32 residual rows) arriving with it, so that neither pushes the shared GEMM operand panels out of
+// an XCD's 4 MiB L2.  It does cut the fabric reads (fc1 199 -> 156 MB per launch together with the row ownership below) -- and the
+// 40-crop tower gets SLOWER, 14.9 -> 15.9 ms: a streamed result also skips the 256 MiB memory-side cache, and the NEXT kernel, which
+// is its only reader, then fetches it from HBM.  `make` leaves it off; tools/build_variants.sh builds the A/B libraries.
+#ifndef SLIME_OPT_NT
+#define SLIME_OPT_NT 0
+#endif
+template <typename V>
+__device__ __forceinline__ void st_stream(V* p, const V v) {
+#if SLIME_OPT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename V>
+__device__ __forceinline__ V ld_stream(const V* p) {
+#if SLIME_OPT_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -165,7 +165,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                 }
                 const u32x4 w = pack8<T>(v);
                 if (in_range(row))
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = w;
+                    st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2), w);
             }
         }
         return;
@@ -173,7 +173,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
     if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32 || EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
         constexpr int BATCH = (MI >= 2) ? 2 : 1;          // 16-row steps per residual batch
         constexpr int NB = MI / BATCH;
-        float4 hb[2][BATCH][NP][2];
+        f32x4 hb[2][BATCH][NP][2];
         float* C = reinterpret_cast<float*>(g.C);
         auto load_batch = [&](int b, int buf) {
 #pragma unroll
@@ -183,8 +183,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const float* src = C + (size_t)row * g.ldc + col_base + 32 * p;
-                    hb[buf][ii][p][0] = *reinterpret_cast<const float4*>(src);
-                    hb[buf][ii][p][1] = *reinterpret_cast<const float4*>(src + 4);
+                    hb[buf][ii][p][0] = ld_stream(reinterpret_cast<const f32x4*>(src));
+                    hb[buf][ii][p][1] = ld_stream(reinterpret_cast<const f32x4*>(src + 4));
                 }
             }
         };
@@ -198,15 +198,15 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                 const int row = row_base + i * 16;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const float4 h0 = hb[b & 1][ii][p][0], h1 = hb[b & 1][ii][p][1];
-                    acc[i][2 * p][0] += bias[p][0] + h0.x; acc[i][2 * p][1] += bias[p][1] + h0.y;
-                    acc[i][2 * p][2] += bias[p][2] + h0.z; acc[i][2 * p][3] += bias[p][3] + h0.w;
-                    acc[i][2 * p + 1][0] += bias[p][4] + h1.x; acc[i][2 * p + 1][1] += bias[p][5] + h1.y;
-                    acc[i][2 * p + 1][2] += bias[p][6] + h1.z; acc[i][2 * p + 1][3] += bias[p][7] + h1.w;
+                    const f32x4 h0 = hb[b & 1][ii][p][0], h1 = hb[b & 1][ii][p][1];
+                    acc[i][2 * p][0] += bias[p][0] + h0[0]; acc[i][2 * p][1] += bias[p][1] + h0[1];
+                    acc[i][2 * p][2] += bias[p][2] + h0[2]; acc[i][2 * p][3] += bias[p][3] + h0[3];
+                    acc[i][2 * p + 1][0] += bias[p][4] + h1[0]; acc[i][2 * p + 1][1] += bias[p][5] + h1[1];
+                    acc[i][2 * p + 1][2] += bias[p][6] + h1[2]; acc[i][2 * p + 1][3] += bias[p][7] + h1[3];
                     if (in_range(row)) {
                         float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
-                        *reinterpret_cast<f32x4*>(o) = acc[i][2 * p];
-                        *reinterpret_cast<f32x4*>(o + 4) = acc[i][2 * p + 1];
+                        st_stream(reinterpret_cast<f32x4*>(o), acc[i][2 * p]);
+                        st_stream(reinterpret_cast<f32x4*>(o + 4), acc[i][2 * p + 1]);
                     }
                 }
                 if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
@@ -222,7 +222,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                             w[0] = T::pack2(acc[i][2 * p][0], acc[i][2 * p][1]); w[1] = T::pack2(acc[i][2 * p][2], acc[i][2 * p][3]);
                             w[2] = T::pack2(acc[i][2 * p + 1][0], acc[i][2 * p + 1][1]); w[3] = T::pack2(acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]);
                             if (in_range(row))
-                                *reinterpret_cast<u32x4*>(g.x16 + ((size_t)row * g.ldx + col_base + 32 * p) * 2) = w;
+                                st_stream(reinterpret_cast<u32x4*>(g.x16 + ((size_t)row * g.ldx + col_base + 32 * p) * 2), w);
                             // sums of the fp32 values (the rounded ones differ by 2^-9 relative per element with random sign:
                             // far below what the statistics need, and unpacking them again would double this loop's VALU work)
 #pragma unroll
@@ -254,7 +254,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                 if constexpr (!FULL) row = min(row, g.M - 1);
 #pragma unroll
                 for (int p = 0; p < NP; ++p)
-                    rb[buf][ii][p] = *reinterpret_cast<const u32x4*>(g.resid + ((size_t)row * g.ldr + col_base + 32 * p) * 2);
+                    rb[buf][ii][p] = ld_stream(reinterpret_cast<const u32x4*>(g.resid + ((size_t)row * g.ldr + col_base + 32 * p) * 2));
             }
         };
         load_batch(0, 0);
@@ -275,7 +275,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                     v[6] = acc[i][2 * p + 1][2] + bias[p][6] + T::lo(r[3]); v[7] = acc[i][2 * p + 1][3] + bias[p][7] + T::hi(r[3]);
                     const u32x4 w = pack8<T>(v);
                     if (in_range(row))
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = w;
+                        st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2), w);
                 }
             }
         }
@@ -314,7 +314,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                 if (in_range(row)) {
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2) = packed[i][p];
+                        st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2), packed[i][p]);
                 }
             }
         } else {
@@ -326,8 +326,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
                         float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
-                        *reinterpret_cast<f32x4*>(o) = acc[i][2 * p];
-                        *reinterpret_cast<f32x4*>(o + 4) = acc[i][2 * p + 1];
+                        st_stream(reinterpret_cast<f32x4*>(o), acc[i][2 * p]);
+                        st_stream(reinterpret_cast<f32x4*>(o + 4), acc[i][2 * p + 1]);
                     }
                 }
             }
@@ -592,6 +592,32 @@ gemm_kernel(GemmArgs g) {
 // in flight => >= 12 slots of flight), one barrier or more before its first reader.  The main
 // loop never drains vmcnt to 0 until no further tile exists.
 // ================================================================================================
+// XCD-owned rows (round 4).  The hardware deals the workgroups of a launch to the 8 XCDs round-robin (workgroup b -> XCD b & 7), and each
+// XCD has its own 4 MiB L2.  XCD x owns a contiguous range of row tiles (as even as 8 allows) and runs ALL their column tiles, so an
+// activation panel crosses the fabric into ONE L2 and a weight panel once per XCD; the grid is padded to 8 x (most row tiles an XCD owns)
+// x tiles_n and the surplus workgroups of the XCDs that own one row tile less exit at once.  N_FAST: the column tiles of a row tile are
+// consecutive (one round = 8 row tiles x 4 column tiles for the N = 1024 GEMMs); otherwise the XCD's row tiles are consecutive.
+// Measured (profiles/r04_fabric_traffic.txt, 20-crop half batch): the ping-pong kernel (fc2: 46 row tiles x 4, ONE round, so uneven
+// ownership costs nothing) reads 255 -> 211 MB per launch across the fabric at unchanged time -- ON.  The direct-B kernel (fc1: 91 row
+// tiles x 16, ~3 rounds) reads 199 -> 156 MB but three XCDs then own 12 row tiles against 11: +9 % work on the critical XCDs, tower
+// 14.9 -> 15.2 ms (two streams) / 16.0 -> 17.1 (one) -- OFF, it keeps the tile-balanced GROUP_M walk.
+#ifndef SLIME_OPT_XCD_ROWS_PP
+#define SLIME_OPT_XCD_ROWS_PP 1
+#endif
+#ifndef SLIME_OPT_XCD_ROWS_DB
+#define SLIME_OPT_XCD_ROWS_DB 0
+#endif
+template <bool N_FAST>
+__device__ __forceinline__ bool xcd_rows_tile(const int tiles_m, const int tiles_n, int& tm, int& tn) {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = tiles_m >> 3, r = tiles_m & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+    if (j >= cnt * tiles_n) return false;
+    if constexpr (N_FAST) { tm = first + j / tiles_n; tn = j % tiles_n; }
+    else { tm = first + j % cnt; tn = j / cnt; }
+    return true;
+}
+static inline int xcd_rows_grid(int tiles_m, int tiles_n) { return 8 * ((tiles_m + 7) / 8) * tiles_n; }
+
 #define PP_BARRIER()                                   \
     do {                                               \
         __builtin_amdgcn_sched_barrier(0);             \
@@ -613,6 +639,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+#if SLIME_OPT_XCD_ROWS_PP
+    int tm, tn;
+    if (!xcd_rows_tile<true>(tiles_m, tiles_n, tm, tn)) return;
+#else
     const int nblk = tiles_m * tiles_n;
     int pid;
     {
@@ -626,6 +656,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     const int gsz = min(tiles_m - first_m, GROUP_M);
     const int tm = first_m + (pid % in_group) % gsz;
     const int tn = (pid % in_group) / gsz;
+#endif
     const int m0 = tm * BM, n0 = tn * BN;
 
     unsigned long long t_start = 0, t_pro = 0, t_loop = 0;
@@ -1028,6 +1059,10 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+#if SLIME_OPT_XCD_ROWS_DB
+    int tm, tn;
+    if (!xcd_rows_tile<false>(tiles_m, tiles_n, tm, tn)) return;
+#else
     const int nblk = tiles_m * tiles_n;
     int pid;
     {
@@ -1040,6 +1075,7 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     const int gsz = min(tiles_m - first_m, GROUP_M);
     const int tm = first_m + (pid % in_group) % gsz;
     const int tn = (pid % in_group) / gsz;
+#endif
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1691,7 +1727,12 @@ static int launch_pp_k(const GemmArgs& g, hipStream_t stream) {
     auto kern = gemm_pp_kernel<T, EPI, KTAG, ABL, MT>;
     SLIME_SET_LDS_ONCE(kern, LDS, "gemm_pp");
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(512), LDS, stream, g);
+#if SLIME_OPT_XCD_ROWS_PP
+    const int grid = xcd_rows_grid(tiles_m, tiles_n);
+#else
+    const int grid = tiles_m * tiles_n;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_pp");
     return SLIME_OK;
 }
@@ -1750,7 +1791,12 @@ static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int LDS = 2 * BM * 64 * 2 + BM * 8;                   // two A stages + the LayerNorm-fold row table
     auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
-    hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), LDS, stream, g);
+#if SLIME_OPT_XCD_ROWS_DB
+    const int grid = xcd_rows_grid(tiles_m, tiles_n);
+#else
+    const int grid = tiles_m * tiles_n;
+#endif
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS, stream, g);
     SLIME_CHECK_LAUNCH("gemm_db");
     return SLIME_OK;
 }

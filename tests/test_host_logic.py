@@ -381,3 +381,64 @@ def test_prefill32_snake_schedule_covers_every_item_once_and_balances(n_kv, batc
     steps = [sum(2 * (qb + 1) for _, _, qb in mine) for mine in sched]
     if (n_kv, batch, nqb, G) in ((8, 8, 19, 256), (8, 1, 145, 256)):             # bench.py --config 4 / 5: 98 vs 95.0, 686 vs 661.6 steps
         assert max(steps) <= 1.04 * sum(steps) / G                               # snake order ~ longest-processing-time first
+
+
+def _xcd_rows_deal(tiles_m, tiles_n, n_fast=True):
+    """gemm.hip:xcd_rows_tile restated: workgroup b of the padded grid -> (row tile, column tile) or None (surplus workgroup)."""
+    grid = 8 * ((tiles_m + 7) // 8) * tiles_n
+    q, r = tiles_m >> 3, tiles_m & 7
+    out = []
+    for b in range(grid):
+        xcd, j = b & 7, b >> 3
+        first = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        cnt = q + (1 if xcd < r else 0)
+        if j >= cnt * tiles_n:
+            out.append(None)
+        elif n_fast:
+            out.append((first + j // tiles_n, j % tiles_n))
+        else:
+            out.append((first + j % cnt, j // cnt))
+    return out
+
+
+@pytest.mark.parametrize("tiles_m,tiles_n", [(46, 4), (91, 4), (1, 4), (3, 4), (8, 4), (12, 1), (23, 4), (181, 4), (46, 16)])
+def test_xcd_owned_rows_deal_covers_every_tile_once_and_keeps_a_row_tile_in_one_l2(tiles_m, tiles_n):
+    """Round 4's tile deal of the ping-pong GEMM (fc2: 46 x 4 tiles at the 20-crop half batch): every tile exactly once; all column
+    tiles of a row tile run on ONE XCD (workgroup id mod 8), back to back, so the activation panel crosses the fabric once; an XCD
+    owns a contiguous run of row tiles, as even as 8 allows; surplus workgroups of the padded grid are < 8 x tiles_n."""
+    for n_fast in (True, False):
+        deal = _xcd_rows_deal(tiles_m, tiles_n, n_fast)
+        real = [t for t in deal if t is not None]
+        assert len(real) == tiles_m * tiles_n and len(set(real)) == len(real)
+        assert len(deal) - len(real) < 8 * tiles_n
+        owner = {}
+        for b, t in enumerate(deal):
+            if t is not None:
+                assert owner.setdefault(t[0], b & 7) == b & 7
+        per_xcd = [sorted(tm for tm, x in owner.items() if x == xcd) for xcd in range(8)]
+        assert all(rows == list(range(rows[0], rows[0] + len(rows))) for rows in per_xcd if rows)
+        assert max(map(len, per_xcd)) - min(map(len, per_xcd)) <= 1
+    deal = _xcd_rows_deal(tiles_m, tiles_n, True)
+    for b, t in enumerate(deal):                                   # N fastest: the column tiles of a row tile are 8 workgroup ids apart
+        if t is not None and t[1] + 1 < tiles_n:
+            assert deal[b + 8] == (t[0], t[1] + 1)
+
+
+@pytest.mark.parametrize("heads,batch,qsplit", [(16, 20, 2), (16, 5, 2), (16, 40, 2), (16, 3, 2), (16, 20, 1), (12, 7, 2), (16, 9, 3)])
+def test_attention_partner_redeal_is_a_bijection_and_pairs_share_an_xcd(heads, batch, qsplit):
+    """attention.hip:attn64r_kernel's re-deal (round 4): launch-order id L -> (head, crop, query part).  Every triple exactly once;
+    when heads x crops is a multiple of 8 the parts of one (crop, head) are ids 8 apart: same XCD, neighbours in dispatch order."""
+    seen = {}
+    for L in range(heads * batch * qsplit):
+        h, b, z = L % heads, (L // heads) % batch, L // (heads * batch)
+        if qsplit > 1 and (heads * batch) % 8 == 0:
+            j = L >> 3
+            p = (j // qsplit) * 8 + (L & 7)
+            z, h, b = j % qsplit, p % heads, p // heads
+        assert (h, b, z) not in seen and h < heads and b < batch and z < qsplit
+        seen[(h, b, z)] = L
+    assert len(seen) == heads * batch * qsplit
+    if qsplit > 1 and (heads * batch) % 8 == 0:
+        for (h, b, z), L in seen.items():
+            if z + 1 < qsplit:
+                assert seen[(h, b, z + 1)] == L + 8
