@@ -40,6 +40,9 @@ static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
 // ------------------------------------------------------------------------------------------------
 // CLIP tower
 // ------------------------------------------------------------------------------------------------
+#ifndef SLIME_OPT_ALIAS_WS
+#define SLIME_OPT_ALIAS_WS 1
+#endif
 struct VitPlan {
     size_t xn, qkv, ctx, ff, h, stats, total;   // offsets
 };
@@ -52,12 +55,25 @@ static VitPlan vit_plan(const slime_vit_desc* d, int n) {
     auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
     p.h = take(M * D * 4);
     p.xn = take(M * D * 2);
-    p.qkv = take(M * 3 * D * 2);
-    p.ctx = take(M * D * 2);
     // ff also hosts the patch-embed staging (im2col operand + fp32 conv output) before the layers
     const size_t ff_bytes = M * (size_t)d->inter * 2;
     const size_t pe_bytes = align_up(Mp * (size_t)d->kpad * 2, 256) + Mp * D * 4;
+#if SLIME_OPT_ALIAS_WS
+    // q/k/v and the attention context die before fc1 writes the MLP's intermediate rows, and those die before the next layer's q/k/v
+    // GEMM: the three share one region (for CLIP-L, 3 D + D = the intermediate width exactly).  The launches of a stream are serial, so
+    // nothing else changes -- except that a 20-crop stream now cycles through 165 MB instead of 260, and the 256 MiB memory-side
+    // cache, which two such streams share, keeps more of what the next kernel reads (profiles/r04_fabric_traffic.txt, section 6).
+    const size_t qkv_bytes = align_up(M * 3 * D * 2, 256), attn_bytes = qkv_bytes + M * D * 2;
+    size_t region = ff_bytes > pe_bytes ? ff_bytes : pe_bytes;
+    if (attn_bytes > region) region = attn_bytes;
+    p.ff = take(region);
+    p.qkv = p.ff;
+    p.ctx = p.ff + qkv_bytes;
+#else
+    p.qkv = take(M * 3 * D * 2);
+    p.ctx = take(M * D * 2);
     p.ff = take(ff_bytes > pe_bytes ? ff_bytes : pe_bytes);
+#endif
     p.stats = take(M * (D / 64) * 2 * sizeof(float));      // LayerNorm fold: (sum, sum of squares) per row and 64-column group
     p.total = align_up(off, 256);
     return p;

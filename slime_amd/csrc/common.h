@@ -102,8 +102,9 @@ __device__ __forceinline__ u32x4 pack8(const float* v) {
 // Measured alternative (round 4, profiles/r04_fabric_traffic.txt), OFF: results leaving with the non-temporal hint (stream / evict
 // first) and read-once inputs (the fp32 residual rows) arriving with it, so that neither pushes the shared GEMM operand panels out of
 // an XCD's 4 MiB L2.  It does cut the fabric reads (fc1 199 -> 156 MB per launch together with the row ownership below) -- and the
-// 40-crop tower gets SLOWER, 14.9 -> 15.9 ms: a streamed result also skips the 256 MiB memory-side cache, and the NEXT kernel, which
-// is its only reader, then fetches it from HBM.  `make` leaves it off; tools/build_variants.sh builds the A/B libraries.
+// 40-crop tower gets SLOWER, 14.9 -> 15.9 ms.  Not separated further; the candidates: a streamed result is not kept for its only
+// reader, the NEXT kernel, and the epilogue's 64-byte row segments leave as partial lines instead of being merged in L2 first.
+// `make` leaves it off; tools/build_variants.sh builds the A/B libraries.
 #ifndef SLIME_OPT_NT
 #define SLIME_OPT_NT 0
 #endif
