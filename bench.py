@@ -48,7 +48,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GF_VIT_PER_CROP = 366.034              # live ViT path, 23 layers, S = 577
-GF_GLOBAL_PER_IMAGE = 54.512           # gated adapter on the global view
+GF_GLOBAL_PER_IMAGE_REFERENCE = 54.512 # gated adapter on the global view as the reference computes it: two complete experts, then the gate mix
+GF_GLOBAL_PER_IMAGE = 35.185           # EXECUTED since round 4: the gate mixes the hidden rows (slime_gate_premix) and projection[2] runs once per
+                                       # token (-2 x 576 x 4096 x 4096 flop per image); rates below are priced on the executed arithmetic
 GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # What the matrix pipes deliver on THIS chip with fresh random bf16 operands in every MFMA and nothing else in the stream (the chip
@@ -397,6 +399,7 @@ def main():
         value = crops_total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         step_gf = n_step * GF_VIT_PER_CROP + IMAGES * GF_GLOBAL_PER_IMAGE + IMAGES * LOCAL * GF_LOCAL_PER_CROP
+        step_gf_reference = step_gf + IMAGES * (GF_GLOBAL_PER_IMAGE_REFERENCE - GF_GLOBAL_PER_IMAGE)
         if prefill:
             step_gf += prefill.gflop
         path_tflops = step_gf * (1 if strong else world) / (elapsed / args.steps) / 1e3
@@ -428,6 +431,9 @@ def main():
                        **extra_cfg},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),
                           "gflop_per_step": round(step_gf, 1),
+                          "gflop_per_step_reference_arithmetic": round(step_gf_reference, 1),
+                          "gflop_note": "rates are priced on the EXECUTED arithmetic: the gated block's second Linear runs once per global token after the gate "
+                                        "mixed the hidden rows (linear map, gates sum to 1/(1+1e-6)); the reference's two complete experts would be the larger figure",
                           "power_capped_mfma_stream_tflops": MFMA_STREAM_AT_POWER_CAP_TFLOPS,
                           "frac_of_power_capped_mfma_stream": round(path_tflops / (MFMA_STREAM_AT_POWER_CAP_TFLOPS * world), 4),
                           "power_note": "the step runs at the 1400 W cap (sclk 1.96 of 2.40 GHz; 13.0 instead of 15.0 ms on all-zero operands): "

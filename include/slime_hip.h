@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 3
+#define SLIME_ABI_VERSION 4
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 
@@ -134,6 +134,13 @@ int slime_attention(const void* q, long q_bs, long q_rs, const void* k, long k_b
  * (GatedBlock.noisy_top_k_gating eval path + mix, projector/builder.py:148,158-165,203-206). */
 int slime_gate_mix(const float* x, int D, const float* w_gate /* [D,2] */, const float* e0,
                    const float* e1, float* out, int rows, int H, void* stream);
+
+/* The same gates on the projection MLP's HIDDEN rows (round 4): out[r, :] = T(g0*a0[r, :] + g1*a1[r, :]) with a0 = GELU(W1 x + b1),
+ * a1 = GELU(W1 attn(x) + b1), T [rows, H]; out may alias a1.  projection[2] is linear and g0 + g1 = 1/(1 + 1e-6), so
+ * projection[2](out) equals the mix of the two expert outputs of projector/builder.py:190-206 up to 1e-6 |b2| -- and runs
+ * over one row per token instead of two.  Gate arithmetic as slime_gate_mix (builder.py:148,158-165). */
+int slime_gate_premix(const float* x, int D, const float* w_gate /* [D,2] */, const void* a0, const void* a1, void* out,
+                      int dtype, int rows, int H, void* stream);
 
 /* Row gather + cast: out[(g*rows_out + r), :] = cast(in[(g*rows_in + row_off + r), :]),
  * g < groups, r < rows_out.  in fp32, out dtype BF16/F16/F32.  (feature_select's [:,1:],

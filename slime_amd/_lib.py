@@ -22,7 +22,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 BF16, F16, F32, U8 = 0, 1, 2, 3
 EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T = range(7)
 
@@ -95,6 +95,7 @@ _SIGNATURES = {
                                         c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "slime_merge_rows_batched": (c_int, [c_void_p, c_long, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
+    "slime_gate_premix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "slime_gate_mix_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long,
                                   c_long, c_void_p]),
     "slime_select_crops": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

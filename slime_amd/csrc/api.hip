@@ -344,16 +344,14 @@ extern "C" int slime_mlp_forward(const slime_mlp_desc* d, const float* x_f32, co
 // ------------------------------------------------------------------------------------------------
 // GatedBlock
 // ------------------------------------------------------------------------------------------------
-struct GatedPlan { size_t e0, e1, rt, mlp, res, total; };
+struct GatedPlan { size_t stack, mlp, res, total; };
 static GatedPlan gated_plan(const slime_mlp_desc* m, const slime_resampler_desc* r, int n) {
     const size_t rows = (size_t)n * r->n_query;
     GatedPlan p{};
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
-    p.e0 = take(rows * m->hidden * 4);
-    p.e1 = take(rows * m->hidden * 4);
-    p.rt = take(rows * m->in_dim * 2);
-    p.mlp = take(mlp_plan(m, (int)rows).total);
+    p.stack = take(2 * rows * m->in_dim * 2);                  // [T(x) | attn(x)]: the MLP's stacked operand
+    p.mlp = take(mlp_plan(m, (int)(2 * rows)).total);
     p.res = take(res_plan(r, n).total);
     p.total = align_up(off, 256);
     return p;
@@ -379,18 +377,25 @@ extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resamp
         return SLIME_EWORKSPACE;
     }
     char* w = (char*)ws;
-    const int rows = n * attn->n_query;
-    const size_t mlp_ws = mlp_plan(mlp, rows).total, res_ws = res_plan(attn, n).total;
-    float* e0 = learnable_gated == 0 ? out : (float*)(w + p.e0);
-    float* e1 = learnable_gated == 1 ? out : (float*)(w + p.e1);
-    if (learnable_gated != 1)                                   // expert 0: projection(x)
-        TRY(slime_mlp_forward(mlp, x, nullptr, rows, e0, w + p.mlp, mlp_ws, stream));
-    if (learnable_gated != 0) {                                 // expert 1: projection(attn(x))
-        TRY(slime_resampler_forward(attn, x, attn->dim, n, nullptr, w + p.rt, w + p.res, res_ws, stream));
-        TRY(slime_mlp_forward(mlp, nullptr, w + p.rt, rows, e1, w + p.mlp, mlp_ws, stream));
-    }
-    if (learnable_gated < 0)
-        TRY(slime_gate_mix(x, mlp->in_dim, w_gate, e0, e1, out, rows, mlp->hidden, stream));
+    const int rows = n * attn->n_query, D = mlp->in_dim, H = mlp->hidden, dt = mlp->dtype;
+    const MlpPlan mp = mlp_plan(mlp, 2 * rows);
+    const size_t res_ws = res_plan(attn, n).total;
+    char* stack = w + p.stack;
+    char* attn_t = stack + (size_t)rows * D * 2;
+    if (learnable_gated == 0)                                   // expert 0: projection(x)
+        return slime_mlp_forward(mlp, x, nullptr, rows, out, w + p.mlp, mp.total, stream);
+    TRY(slime_resampler_forward(attn, x, attn->dim, n, nullptr, attn_t, w + p.res, res_ws, stream));
+    if (learnable_gated == 1)                                   // expert 1: projection(attn(x))
+        return slime_mlp_forward(mlp, nullptr, attn_t, rows, out, w + p.mlp, mp.total, stream);
+    // Both experts, mixed by the gate (builder.py:190-206).  projection[0] + GELU run over the stacked rows [T(x) | attn(x)]; the gate
+    // mixes the HIDDEN rows (slime_gate_premix: projection[2] is linear and g0 + g1 = 1 / (1 + 1e-6)), so projection[2] runs over ONE
+    // row per token and writes the block's output directly -- a third less GEMM work than two complete experts (round 4).
+    char* mid = w + p.mlp + mp.mid;
+    TRY(slime_layernorm(x, D, rows, D, nullptr, nullptr, 0.f, 0, nullptr, stack, nullptr, nullptr, 0, dt, stream));
+    TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, 2 * rows, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
+    char* mixed = mid + (size_t)rows * H * 2;
+    TRY(slime_gate_premix(x, D, w_gate, mid, mixed, mixed, dt, rows, H, stream));
+    TRY(gemm_w(mixed, H, mlp->w2, mlp->w2_frag, mlp->b2, out, H, rows, H, H, dt, SLIME_EPI_BIAS_F32, stream));
     return SLIME_OK;
 }
 
@@ -459,7 +464,6 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
     float* xl32 = (float*)(w + p.xl32);
     char* stack = w + p.stack;
     float* e = (float*)(w + p.e);
-    const size_t mlp_ws = mlp_plan(mlp, (int)p.rows_all).total;
     const int period = 1 + n_local;
 
     // stacked MLP input: [x_global | attn(x_global) | post_qformer(x_local)] (segments that are not needed are dropped)
@@ -479,19 +483,25 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
         TRY(slime_resampler_forward(post, xl32, D, n_images * n_local, nullptr, stack + (size_t)seg_local * D * 2, w + p.res,
                                     res_plan(post, n_images * n_local).total, stream));
     }
-    TRY(slime_mlp_forward(mlp, nullptr, stack, (int)p.rows_all, e, w + p.mlp, mlp_ws, stream));
-
-    // global tokens -> rows [0, P) of every image
+    // projection MLP over the stack.  With both experts (learnable_gated < 0) the gate mixes the HIDDEN rows of the two global
+    // segments (slime_gate_premix, into the second one) and projection[2] runs over [mixed global | local] = one row per output
+    // token; e then holds [global | local] rows.  Otherwise e holds the stack's rows.
+    const MlpPlan mp = mlp_plan(mlp, (int)p.rows_all);
+    char* mid = w + p.mlp + mp.mid;
+    TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
+    long e_glob = 0, e_local = seg_local;                       // rows of e
     if (learnable_gated < 0) {
-        TRY(slime_gate_mix_ex(xg32, D, w_gate, e + (size_t)seg_x * H, e + (size_t)seg_attn * H, out, out_dtype, (int)p.rows_g, H,
-                              P, out_image_stride, 0, stream));
+        char* mixed = mid + (size_t)seg_attn * H * 2;
+        TRY(slime_gate_premix(xg32, D, w_gate, mid + (size_t)seg_x * H * 2, mixed, mixed, dt, (int)p.rows_g, H, stream));
+        TRY(gemm_w(mixed, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)(p.rows_g + p.rows_l), H, H, dt, SLIME_EPI_BIAS_F32, stream));
+        e_local = p.rows_g;
     } else {
-        const long seg = learnable_gated == 0 ? seg_x : seg_attn;
-        // flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)
-        TRY(slime_merge_rows_batched(e + (size_t)seg * H, P, out, out_dtype, out_image_stride, 0, n_images, P, 1, 1, H, 0, stream));
+        TRY(gemm_w(mid, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)p.rows_all, H, H, dt, SLIME_EPI_BIAS_F32, stream));
     }
+    // global tokens -> rows [0, P) of every image: flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)
+    TRY(slime_merge_rows_batched(e + (size_t)e_glob * H, P, out, out_dtype, out_image_stride, 0, n_images, P, 1, 1, H, 0, stream));
     if (post)
-        TRY(slime_merge_rows_batched(e + (size_t)seg_local * H, (long)n_local * post->n_query, out, out_dtype, out_image_stride, P,
+        TRY(slime_merge_rows_batched(e + (size_t)e_local * H, (long)n_local * post->n_query, out, out_dtype, out_image_stride, P,
                                      n_images, nw, nh, g, H, merge, stream));
     return SLIME_OK;
 }

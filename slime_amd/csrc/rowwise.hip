@@ -343,6 +343,58 @@ extern "C" int slime_gate_mix_ex(const float* x, int D, const float* w_gate, con
     return SLIME_OK;
 }
 
+// The same gates applied to the MLP's HIDDEN rows (round 4): the projector's second Linear is linear and g0 + g1 = 1 / (1 + 1e-6), so
+// W2 (g0 a0 + g1 a1) + b2 replaces g0 (W2 a0 + b2) + g1 (W2 a1 + b2) -- the second Linear then runs over ONE row per token instead of
+// two.  a0 / a1 / out: T [rows, H]; out may be a1 (each thread reads its elements before it writes them).  The gate arithmetic is
+// gate_mix_kernel's, instruction for instruction.
+template <typename T>
+__global__ void __launch_bounds__(256) gate_premix_kernel(const float* x, int D, const float* wg, const char* a0, const char* a1,
+                                                          char* out, int rows, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float l0 = 0.f, l1 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xv = xr[c];
+        const float2 w = *reinterpret_cast<const float2*>(wg + 2 * c);
+        l0 += xv * w.x; l1 += xv * w.y;
+    }
+    l0 = wave_sum(l0); l1 = wave_sum(l1);
+    const float m = fmaxf(l0, l1);
+    const float p0 = expf(l0 - m), p1 = expf(l1 - m);
+    const float ps = p0 + p1;
+    const float s0 = p0 / ps, s1 = p1 / ps;            // softmax
+    const float den = s0 + s1 + 1e-6f;                 // top-2-of-2 renormalisation
+    const float g0 = s0 / den, g1 = s1 / den;
+    const size_t base = (size_t)row * H * 2;
+    for (int c = lane * 8; c < H; c += 512) {
+        const u32x4 u = *reinterpret_cast<const u32x4*>(a0 + base + (size_t)c * 2);
+        const u32x4 w = *reinterpret_cast<const u32x4*>(a1 + base + (size_t)c * 2);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = g0 * T::lo(u[k]) + g1 * T::lo(w[k]);
+            v[2 * k + 1] = g0 * T::hi(u[k]) + g1 * T::hi(w[k]);
+        }
+        *reinterpret_cast<u32x4*>(out + base + (size_t)c * 2) = pack8<T>(v);
+    }
+}
+
+extern "C" int slime_gate_premix(const float* x, int D, const float* w_gate, const void* a0, const void* a1, void* out, int dtype,
+                                 int rows, int H, void* stream) {
+    SLIME_REQUIRE(x && w_gate && a0 && a1 && out && rows > 0 && H > 0 && H % 8 == 0, "gate_premix: bad input");
+    SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "gate_premix: dtype must be BF16 or F16");
+    if (dtype == SLIME_F16)
+        hipLaunchKernelGGL(gate_premix_kernel<F16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate,
+                           (const char*)a0, (const char*)a1, (char*)out, rows, H);
+    else
+        hipLaunchKernelGGL(gate_premix_kernel<BF16>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate,
+                           (const char*)a0, (const char*)a1, (char*)out, rows, H);
+    SLIME_CHECK_LAUNCH("gate_premix");
+    return SLIME_OK;
+}
+
 extern "C" int slime_gate_mix(const float* x, int D, const float* w_gate, const float* e0, const float* e1,
                               float* out, int rows, int H, void* stream) {
     return slime_gate_mix_ex(x, D, w_gate, e0, e1, out, SLIME_F32, rows, H, rows > 0 ? rows : 1, 0, 0, stream);

@@ -415,6 +415,44 @@ def test_im2col_and_embed(dev):
         assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gate_premix_hidden_rows(dev, dt):
+    """slime_gate_premix (round 4): out = T(g0 a0 + g1 a1) on the MLP's hidden rows with slime_gate_mix's gates -- and, since
+    projection[2] is linear with g0 + g1 = 1 / (1 + 1e-6), projection[2](out) equals the gate mix of the two expert OUTPUTS
+    (projector/builder.py:190-206) to fp32 accuracy when the operands are the same.  In place over a1 as the adapter uses it."""
+    from slime_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for rows, D, H in ((576, 128, 256), (1153, 1024, 4096)):
+        x = _rand((rows, D), torch.float32, dev, 31)
+        wg = _rand((D, 2), torch.float32, dev, 32, 0.2)
+        a0 = _rand((rows, H), torch.float32, dev, 33).to(dt)
+        a1 = _rand((rows, H), torch.float32, dev, 34).to(dt)
+        # reference gates in float64 on the host (torch's fp32 matmul on the device is not the yardstick for a max-norm bound)
+        p = torch.softmax(x.double().cpu() @ wg.double().cpu(), 1)
+        gts = p / (p.sum(1, keepdim=True) + 1e-6)
+        want = (gts[:, :1] * a0.double().cpu() + gts[:, 1:] * a1.double().cpu())[:-1]
+        out = a1.clone()                                                       # in place over a1
+        guard = out.clone()
+        _lib.check(lib.slime_gate_premix(x.data_ptr(), D, wg.data_ptr(), a0.data_ptr(), out.data_ptr(), out.data_ptr(),
+                                         _lib.BF16 if dt == torch.bfloat16 else _lib.F16, rows - 1, H, st))
+        assert torch.equal(out[-1], guard[-1])                                 # rows past `rows` untouched
+        got = out[:-1].double().cpu()
+        # one rounding to T of an fp32 value computed from the same operands: half a spacing of T (relative 2^-8 bf16, 2^-11 fp16) of
+        # the result, plus the fp32 gate arithmetic (logit sums over D terms, expf: ~1e-5 relative) on each PRODUCT -- the two may cancel
+        half = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+        mag = (gts[:, :1] * a0.double().cpu()).abs()[:-1] + (gts[:, 1:] * a1.double().cpu()).abs()[:-1]
+        excess = (got - want).abs() - (1.02 * half * want.abs() + 3e-5 * mag + 1e-7)
+        i = int(excess.argmax())
+        assert float(excess.max()) <= 0, (rows, D, H, float(excess.max()), float(got.flatten()[i]), float(want.flatten()[i]), gts[i // H].tolist())
+        assert rel_l2(got.float(), want.float()) < (3e-3 if dt == torch.bfloat16 else 4e-4)
+        # linearity: W2 (g0 a0 + g1 a1) + b2 == g0 (W2 a0 + b2) + g1 (W2 a1 + b2) up to 1e-6 |b2| (float64 reference arithmetic)
+        W2 = _rand((64, H), torch.float32, dev, 35, H ** -0.5).double().cpu(); b2 = _rand((64,), torch.float32, dev, 36).double().cpu()
+        a0d, a1d = a0.double().cpu()[:-1], a1.double().cpu()[:-1]
+        mix_out = gts[:-1, :1] * (a0d @ W2.T + b2) + gts[:-1, 1:] * (a1d @ W2.T + b2)
+        assert rel_l2((want @ W2.T + b2).float(), mix_out.float()) < 5e-6
+
+
 def test_gate_mix_gather_merge(dev):
     from slime_amd import ops, _lib
     lib = _lib.load()

@@ -28,7 +28,7 @@ def test_library_exports_exactly_the_header():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(lib, s), f"libslime_hip.so does not export {s}"
-    assert lib.slime_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.slime_abi_version() == _lib.ABI_VERSION == 4
     assert _exported(_lib.LIB_PATH) == syms
     assert set(_lib._SIGNATURES) == syms, "slime_amd/_lib.py binds exactly the header's functions"
     if os.path.exists(_lib.DIAG_LIB_PATH):
