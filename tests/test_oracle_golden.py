@@ -71,6 +71,29 @@ def test_gated_variants(tiny):
     assert np.array_equal(pos.numpy()[::5, ::3], g["abs_pos_12_to_24"])
 
 
+def test_gate_mix_on_hidden_rows_reproduces_the_reference_output(tiny):
+    """The arithmetic slime_gated_forward / slime_adapter_forward run since round 4 (slime_gate_premix): the gates applied to the
+    projection MLP's HIDDEN rows, projection[2] once per token.  Restated in fp32 on the oracle's pieces and held against the golden
+    vector the REFERENCE's GatedBlock.forward produced (projector/builder.py:190-206: two complete experts, then the mix): the
+    identity W2 (g0 a0 + g1 a1) + b2 = g0 (W2 a0 + b2) + g1 (W2 a1 + b2) - (1 - g0 - g1) b2, with g0 + g1 = 1 / (1 + 1e-6)."""
+    import torch.nn.functional as F
+    g, tsd, asd = tiny
+    proj = W.sub_state(asd, "mm_projector.")
+    feats = O.tower_forward(tsd, W.TINY, W.synthetic_pixels(2, seed=31)).float()
+    H = W.ADAPTER_TINY.num_heads
+    attn_sd = {k[len("attn."):]: v for k, v in proj.items() if k.startswith("attn.")}
+    w1, b1 = proj["projection.0.weight"].float(), proj["projection.0.bias"].float()
+    w2, b2 = proj["projection.2.weight"].float(), proj["projection.2.bias"].float()
+    a0 = F.gelu(F.linear(feats, w1, b1))
+    a1 = F.gelu(F.linear(O.resampler_forward(attn_sd, feats, H), w1, b1))
+    N, C, D = feats.shape
+    gt = O.gate_weights(proj, feats.reshape(N * C, D)).reshape(N, C, 2)
+    assert float((gt.sum(-1) - 1.0 / (1.0 + 1e-6)).abs().max()) < 1e-6
+    out = F.linear(gt[..., 0:1] * a0 + gt[..., 1:2] * a1, w2, b2)
+    assert rel_l2(out[:, ::7, ::5], g["batched_gated"]) < TOL
+    assert rel_l2(out, O.gated_block_forward(proj, feats, H)) < 2e-6
+
+
 @pytest.mark.parametrize("n_local,size", [(4, (672, 672)), (6, (1344, 1344))])
 def test_full_dims(n_local, size):
     """ViT-L/14-336 + 1024->4096 adapter geometry, sub-sampled tensors and per-crop statistics."""
