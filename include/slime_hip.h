@@ -48,7 +48,8 @@ enum {
     SLIME_EPI_BIAS_F32,          /* -> fp32                                                              */
     SLIME_EPI_BIAS_RESID_F32,    /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
     SLIME_EPI_BIAS_RESID_F32_LN, /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
-    SLIME_EPI_BIAS_RESID_T       /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
+    SLIME_EPI_BIAS_RESID_T,      /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
+    SLIME_EPI_BIAS_GELU_MIX_T    /* C[t] = T(g0[t] gelu(A[t] B^T + bias) + g1[t] gelu(A2[t] B^T + bias)): GatedBlock hidden rows, mixed in fp32 (slime_gemm_ex) */
 };
 
 int slime_abi_version(void);
@@ -79,8 +80,14 @@ typedef struct {
     void* x16; int ldx; float* stats_out;                                             /* producer side, or NULL / 0 */
     const void* B_frag;          /* optional: B in MFMA-fragment order (slime_gemm_pack_b), or NULL                  */
     const void* resid; int ldr;  /* epilogue BIAS_RESID_T: residual rows T [M, ldr] (may alias C), else NULL / 0     */
+    const void* A2;              /* epilogue BIAS_GELU_MIX_T: the second expert's operand rows T [M, lda], else NULL  */
+    const float* mix_gates;      /* epilogue BIAS_GELU_MIX_T: fp32 [M, 2] gate pair per row (slime_gate_weights)      */
 } slime_gemm_args;
 int slime_gemm_ex(const slime_gemm_args* args, void* stream);
+/* Epilogue SLIME_EPI_BIAS_GELU_MIX_T (round 4; needs B_frag, N % 256 == 0): ONE launch computes projection[0] + GELU of BOTH experts'
+ * rows of a token (A = T(x), A2 = attn(x): a workgroup's 128-row tile is 64 rows of A and the same 64 rows of A2, so a lane holds
+ * both results of a token) and stores their gate mix, rounded once: C[t, :] = T(g0 a0 + g1 a1), M = tokens.  projection[2] applied to
+ * C equals the mix of the two expert outputs (GatedBlock.forward, projector/builder.py:190-206) up to 1e-6 |b2|, see slime_gate_premix. */
 
 /* A STATIC B operand (nn.Linear weights: every GEMM of this path) can additionally be handed over in MFMA-fragment order:
  * out[((t*(K/32) + s)*4 + f)*64 + lane] (16-byte units) = B[64t + 32(f>>1) + 8((lane&15)>>2) + 4(f&1) + (lane&3)][32s + 8(lane>>4) .. +8].
@@ -141,6 +148,10 @@ int slime_gate_mix(const float* x, int D, const float* w_gate /* [D,2] */, const
  * over one row per token instead of two.  Gate arithmetic as slime_gate_mix (builder.py:148,158-165). */
 int slime_gate_premix(const float* x, int D, const float* w_gate /* [D,2] */, const void* a0, const void* a1, void* out,
                       int dtype, int rows, int H, void* stream);
+
+/* The gate pair alone: out[r] = (g0, g1) = softmax(x[r,:] @ w_gate) / (sum + 1e-6), fp32 [rows, 2] (builder.py:148,158-165);
+ * the operand `mix_gates` of the SLIME_EPI_BIAS_GELU_MIX_T epilogue.  Arithmetic as slime_gate_mix / slime_gate_premix. */
+int slime_gate_weights(const float* x, int D, const float* w_gate /* [D,2] */, float* out, int rows, void* stream);
 
 /* Row gather + cast: out[(g*rows_out + r), :] = cast(in[(g*rows_in + row_off + r), :]),
  * g < groups, r < rows_out.  in fp32, out dtype BF16/F16/F32.  (feature_select's [:,1:],

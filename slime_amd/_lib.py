@@ -24,7 +24,8 @@ CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 4
 BF16, F16, F32, U8 = 0, 1, 2, 3
-EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T = range(7)
+(EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T,
+ EPI_BIAS_GELU_MIX_T) = range(8)
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -44,7 +45,8 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int), ("B", c_void_p), ("bias", c_void_p), ("C", c_void_p), ("ldc", c_int),
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
-                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int)]
+                ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int),
+                ("A2", c_void_p), ("mix_gates", c_void_p)]
 
 
 class ResamplerDesc(C.Structure):
@@ -95,6 +97,7 @@ _SIGNATURES = {
                                         c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "slime_merge_rows_batched": (c_int, [c_void_p, c_long, c_void_p, c_int, c_long, c_long, c_int, c_int, c_int, c_int, c_int,
                                          c_int, c_void_p]),
+    "slime_gate_weights": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "slime_gate_premix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "slime_gate_mix_ex": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_long,
                                   c_long, c_void_p]),

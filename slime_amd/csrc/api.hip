@@ -25,6 +25,17 @@ static int gemm_w(const void* A, int lda, const void* B, const void* B_frag, con
     return slime_gemm_ex(&a, stream);
 }
 
+// projection[0] + GELU of both experts' rows and their gate mix in ONE launch (SLIME_EPI_BIAS_GELU_MIX_T; direct-B kernel only)
+static bool mix_in_gemm(const slime_mlp_desc* m) {
+    return m->w1_frag && m->hidden % 256 == 0 && m->in_dim % 64 == 0 && ((uintptr_t)m->w1_frag % 16) == 0;
+}
+static int gemm_mix(const void* A, const void* A2, const float* gates, const slime_mlp_desc* m, void* C, int tokens, void* stream) {
+    slime_gemm_args a{};
+    a.A = A; a.A2 = A2; a.mix_gates = gates; a.lda = m->in_dim; a.B = m->w1; a.B_frag = m->w1_frag; a.bias = m->b1; a.C = C; a.ldc = m->hidden;
+    a.M = tokens; a.N = m->hidden; a.K = m->in_dim; a.dtype = m->dtype; a.epilogue = SLIME_EPI_BIAS_GELU_MIX_T;
+    return slime_gemm_ex(&a, stream);
+}
+
 extern "C" int slime_abi_version(void) { return SLIME_ABI_VERSION; }
 
 #define TRY(call)                     \
@@ -344,7 +355,7 @@ extern "C" int slime_mlp_forward(const slime_mlp_desc* d, const float* x_f32, co
 // ------------------------------------------------------------------------------------------------
 // GatedBlock
 // ------------------------------------------------------------------------------------------------
-struct GatedPlan { size_t stack, mlp, res, total; };
+struct GatedPlan { size_t stack, mlp, res, gates, total; };
 static GatedPlan gated_plan(const slime_mlp_desc* m, const slime_resampler_desc* r, int n) {
     const size_t rows = (size_t)n * r->n_query;
     GatedPlan p{};
@@ -353,6 +364,7 @@ static GatedPlan gated_plan(const slime_mlp_desc* m, const slime_resampler_desc*
     p.stack = take(2 * rows * m->in_dim * 2);                  // [T(x) | attn(x)]: the MLP's stacked operand
     p.mlp = take(mlp_plan(m, (int)(2 * rows)).total);
     p.res = take(res_plan(r, n).total);
+    p.gates = take(rows * 2 * sizeof(float));
     p.total = align_up(off, 256);
     return p;
 }
@@ -391,10 +403,17 @@ extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resamp
     // mixes the HIDDEN rows (slime_gate_premix: projection[2] is linear and g0 + g1 = 1 / (1 + 1e-6)), so projection[2] runs over ONE
     // row per token and writes the block's output directly -- a third less GEMM work than two complete experts (round 4).
     char* mid = w + p.mlp + mp.mid;
-    TRY(slime_layernorm(x, D, rows, D, nullptr, nullptr, 0.f, 0, nullptr, stack, nullptr, nullptr, 0, dt, stream));
-    TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, 2 * rows, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
     char* mixed = mid + (size_t)rows * H * 2;
-    TRY(slime_gate_premix(x, D, w_gate, mid, mixed, mixed, dt, rows, H, stream));
+    TRY(slime_layernorm(x, D, rows, D, nullptr, nullptr, 0.f, 0, nullptr, stack, nullptr, nullptr, 0, dt, stream));
+    if (mix_in_gemm(mlp)) {
+        // the mix in fp32 inside projection[0]'s epilogue (one rounding, no pass over the hidden rows): SLIME_EPI_BIAS_GELU_MIX_T
+        float* gates = (float*)(w + p.gates);
+        TRY(slime_gate_weights(x, D, w_gate, gates, rows, stream));
+        TRY(gemm_mix(stack, attn_t, gates, mlp, mixed, rows, stream));
+    } else {
+        TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, 2 * rows, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
+        TRY(slime_gate_premix(x, D, w_gate, mid, mixed, mixed, dt, rows, H, stream));
+    }
     TRY(gemm_w(mixed, H, mlp->w2, mlp->w2_frag, mlp->b2, out, H, rows, H, H, dt, SLIME_EPI_BIAS_F32, stream));
     return SLIME_OK;
 }
@@ -402,7 +421,7 @@ extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resamp
 // ------------------------------------------------------------------------------------------------
 // Fused adapter (GatedBlock on the global crops + post_qformer/MLP/merge on the local crops)
 // ------------------------------------------------------------------------------------------------
-struct AdapterPlan { size_t xg32, xl32, stack, e, mlp, res, total; long rows_g, rows_l, rows_all; int segs_g; };
+struct AdapterPlan { size_t xg32, xl32, stack, e, mlp, res, gates, total; long rows_g, rows_l, rows_all; int segs_g; };
 static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_desc* attn, const slime_resampler_desc* post,
                                 int n_images, int n_local, int learnable_gated) {
     AdapterPlan p{};
@@ -421,6 +440,7 @@ static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_d
     size_t res = res_plan(attn, n_images).total;
     if (post && n_local > 0) { const size_t r2 = res_plan(post, n_images * n_local).total; if (r2 > res) res = r2; }
     p.res = take(res);
+    p.gates = take((size_t)p.rows_g * 2 * sizeof(float));
     p.total = align_up(off, 256);
     return p;
 }
@@ -488,14 +508,26 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
     // token; e then holds [global | local] rows.  Otherwise e holds the stack's rows.
     const MlpPlan mp = mlp_plan(mlp, (int)p.rows_all);
     char* mid = w + p.mlp + mp.mid;
-    TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
     long e_glob = 0, e_local = seg_local;                       // rows of e
     if (learnable_gated < 0) {
         char* mixed = mid + (size_t)seg_attn * H * 2;
-        TRY(slime_gate_premix(xg32, D, w_gate, mid + (size_t)seg_x * H * 2, mixed, mixed, dt, (int)p.rows_g, H, stream));
+        if (mix_in_gemm(mlp)) {
+            // the mix in fp32 inside projection[0]'s epilogue (SLIME_EPI_BIAS_GELU_MIX_T: one rounding, no pass over the hidden rows,
+            // half the global hidden rows written); the local rows follow in their own launch, directly behind the mixed rows
+            float* gates = (float*)(w + p.gates);
+            TRY(slime_gate_weights(xg32, D, w_gate, gates, (int)p.rows_g, stream));
+            TRY(gemm_mix(stack + (size_t)seg_x * D * 2, stack + (size_t)seg_attn * D * 2, gates, mlp, mixed, (int)p.rows_g, stream));
+            if (post)
+                TRY(gemm_w(stack + (size_t)seg_local * D * 2, D, mlp->w1, mlp->w1_frag, mlp->b1, mid + (size_t)seg_local * H * 2, H,
+                           (int)p.rows_l, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
+        } else {
+            TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
+            TRY(slime_gate_premix(xg32, D, w_gate, mid + (size_t)seg_x * H * 2, mixed, mixed, dt, (int)p.rows_g, H, stream));
+        }
         TRY(gemm_w(mixed, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)(p.rows_g + p.rows_l), H, H, dt, SLIME_EPI_BIAS_F32, stream));
         e_local = p.rows_g;
     } else {
+        TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
         TRY(gemm_w(mid, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)p.rows_all, H, H, dt, SLIME_EPI_BIAS_F32, stream));
     }
     // global tokens -> rows [0, P) of every image: flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)

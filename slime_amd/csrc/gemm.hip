@@ -335,6 +335,42 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
     }
 }
 
+// Epilogue BIAS_GELU_MIX_T (direct-B kernel only; round 4): the workgroup's 128-row operand tile is 64 rows of A (the token rows x)
+// on top of the same 64 rows of A2 (their attention expert), so accumulator blocks i and i + 4 of a lane belong to ONE token.  Both
+// get bias + erf-GELU, the gate pair of the token mixes them in fp32, and the mix is rounded to T once: C[token] = T(g0 a0 + g1 a1).
+template <typename T>
+__device__ __forceinline__ void epilogue_mix(const GemmArgs& g, f32x4 (&acc)[8][4], const int tok0, const int li, const int col_base) {
+    float bias[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (g.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(g.bias + col_base + 32 * p);
+            const float4 b1 = *reinterpret_cast<const float4*>(g.bias + col_base + 32 * p + 4);
+            bias[p][0] = b0.x; bias[p][1] = b0.y; bias[p][2] = b0.z; bias[p][3] = b0.w;
+            bias[p][4] = b1.x; bias[p][5] = b1.y; bias[p][6] = b1.z; bias[p][7] = b1.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bias[p][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tok = tok0 + 16 * i + li;
+        const float2 gt = *reinterpret_cast<const float2*>(g.mix_gates + 2 * (size_t)min(tok, g.M - 1));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = gt.x * gelu_erf(acc[i][2 * p][j] + bias[p][j]) + gt.y * gelu_erf(acc[i + 4][2 * p][j] + bias[p][j]);
+                v[4 + j] = gt.x * gelu_erf(acc[i][2 * p + 1][j] + bias[p][4 + j]) + gt.y * gelu_erf(acc[i + 4][2 * p + 1][j] + bias[p][4 + j]);
+            }
+            if (tok < g.M)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)tok * g.ldc + col_base + 32 * p) * 2) = pack8<T>(v);
+        }
+    }
+}
+
 // Epilogue dispatch shared by every kernel: FULL-tile fast path or ragged last row tile; LayerNorm-fold variant when the call
 // carries row statistics (only the two epilogues the tower uses it with are instantiated).
 template <typename T, int EPI, int MI, int NI>
@@ -1056,9 +1092,13 @@ template <typename T, int EPI, int KTAG, int MI>
 __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     constexpr int NJ = 4, BM = 16 * MI, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = MI / 2;
     static_assert(MI == 8 || MI == 4, "direct-B tile heights: 128 or 64 rows");
+    // BIAS_GELU_MIX_T: a tile holds TROWS = 64 tokens -- their rows of A in its upper half, of A2 in its lower half (epilogue_mix)
+    constexpr bool MIX = EPI == SLIME_EPI_BIAS_GELU_MIX_T;
+    static_assert(!MIX || MI == 8, "the mix epilogue pairs accumulator blocks i and i + 4 of a 128-row tile");
+    constexpr int TROWS = MIX ? BM / 2 : BM;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / BN;
+    const int tiles_m = (g.M + TROWS - 1) / TROWS, tiles_n = g.N / BN;
 #if SLIME_OPT_XCD_ROWS_DB
     int tm, tn;
     if (!xcd_rows_tile<false>(tiles_m, tiles_n, tm, tn)) return;
@@ -1076,7 +1116,7 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     const int tm = first_m + (pid % in_group) % gsz;
     const int tn = (pid % in_group) / gsz;
 #endif
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TROWS, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's 64-column slice
@@ -1086,14 +1126,16 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     unsigned soff[AP];
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
-        const int row = (wave + 4 * j) * 8 + lrow;
+        const int row = ((wave + 4 * j) * 8 + lrow) & (TROWS - 1);    // MIX: pieces 8..15 (j >= AP / 2) hold the same tokens, read from A2
         const int rl = min(row, g.M - 1 - m0);                       // clamp: rows past M re-read the last row
         soff[j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
     }
     const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
+    const char* a_gbase2 = MIX ? g.A2 + (size_t)m0 * g.lda * 2 : a_gbase;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem));
     auto dma = [&](int j, int tile) {
-        lds_dma16(soff[j], uniform_ptr(a_gbase + (size_t)tile * (BK * 2)), lds0 + (tile & 1) * A_BYTES + (wave + 4 * j) * 1024);
+        lds_dma16(soff[j], uniform_ptr((MIX && j >= AP / 2 ? a_gbase2 : a_gbase) + (size_t)tile * (BK * 2)),
+                  lds0 + (tile & 1) * A_BYTES + (wave + 4 * j) * 1024);
     };
     // this wave's weight stream: 4 KiB per k-step, contiguous over k-steps
     const char* bw = uniform_ptr(g.Bf + ((size_t)(n0 / 64 + wave) * (size_t)(g.K / 32)) * 4096);
@@ -1196,9 +1238,10 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
 #ifdef SLIME_DIAG
     if (g.db_abl & 4) __builtin_amdgcn_s_setprio(3);
     if (g.db_abl & 2) return;
-    if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; }
+    if constexpr (!MIX) { if (g.db_abl & 1) { run_epilogue<T, EPI, MI, NJ>(g, acc, li, n0 + wave * 64 + 8 * lq, true, lnrow + 2 * li); return; } }
 #endif
-    run_epilogue<T, EPI, MI, NJ>(g, acc, m0 + li, n0 + wave * 64 + 8 * lq, m0 + BM <= g.M, lnrow + 2 * li);
+    if constexpr (MIX) epilogue_mix<T>(g, acc, m0, li, n0 + wave * 64 + 8 * lq);
+    else run_epilogue<T, EPI, MI, NJ>(g, acc, m0 + li, n0 + wave * 64 + 8 * lq, m0 + BM <= g.M, lnrow + 2 * li);
 }
 
 // Static-operand layout of gemm_db_kernel: out[((t * (K/32) + s) * 4 + nj) * 64 + lane] (16-byte units) =
@@ -1790,7 +1833,8 @@ static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
     constexpr int BM = 16 * MI;
     constexpr int LDS = 2 * BM * 64 * 2 + BM * 8;                   // two A stages + the LayerNorm-fold row table
     auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = g.N / 256;
+    constexpr int TROWS = EPI == SLIME_EPI_BIAS_GELU_MIX_T ? BM / 2 : BM;       // tokens per tile (gemm_db_kernel)
+    const int tiles_m = (g.M + TROWS - 1) / TROWS, tiles_n = g.N / 256;
 #if SLIME_OPT_XCD_ROWS_DB
     const int grid = xcd_rows_grid(tiles_m, tiles_n);
 #else
@@ -1937,6 +1981,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
         case SLIME_EPI_BIAS_RESID_F32: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32>(g, stream);
         case SLIME_EPI_BIAS_RESID_F32_LN: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32_LN>(g, stream);
         case SLIME_EPI_BIAS_RESID_T: return launch_epi<T, SLIME_EPI_BIAS_RESID_T>(g, stream);
+        case SLIME_EPI_BIAS_GELU_MIX_T: return launch_db<T, SLIME_EPI_BIAS_GELU_MIX_T, 8>(g, stream);    // direct-B only (checked by slime_gemm_ex)
     }
     slime_set_error("gemm: unknown epilogue %d", epi);
     return SLIME_EINVAL;
@@ -1983,9 +2028,12 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
                       "gemm: BIAS_RESID_T needs resid T [M, ldr >= N] (16-byte aligned, ldr a multiple of 8)");
     // the fragment-order copy of B is optional; it is only usable with whole 64-column tiles, >= 2 k-steps per tile and 32-bit A offsets
     const bool frag_ok = a->B_frag && N % 256 == 0 && ((uintptr_t)a->B_frag % 16) == 0 && (size_t)128 * lda * 2 < (1ull << 32);
+    if (a->epilogue == SLIME_EPI_BIAS_GELU_MIX_T)
+        SLIME_REQUIRE(frag_ok && a->A2 && a->mix_gates && ((uintptr_t)a->A2 % 16) == 0 && ((uintptr_t)a->mix_gates % 8) == 0 && !a->ln_stats,
+                      "gemm: BIAS_GELU_MIX_T runs on the direct-B kernel only: needs B_frag (N %% 256 == 0), A2 [M, lda] and mix_gates [M, 2]");
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
                a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
-               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr};
+               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr, (const char*)a->A2, a->mix_gates};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);
@@ -2008,8 +2056,8 @@ extern "C" int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* s
 
 extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
                           int M, int N, int K, int dtype, int epilogue, void* stream) {
-    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN && epilogue != SLIME_EPI_BIAS_RESID_T,
-                  "gemm: BIAS_RESID_F32_LN / BIAS_RESID_T take extra operands: use slime_gemm_ex");
+    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN && epilogue != SLIME_EPI_BIAS_RESID_T && epilogue != SLIME_EPI_BIAS_GELU_MIX_T,
+                  "gemm: BIAS_RESID_F32_LN / BIAS_RESID_T / BIAS_GELU_MIX_T take extra operands: use slime_gemm_ex");
     slime_gemm_args a{};
     a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.dtype = dtype; a.epilogue = epilogue;
     return slime_gemm_ex(&a, stream);

@@ -22,6 +22,8 @@ struct GemmArgs {
     int db_abl;
     // epilogue BIAS_RESID_T: 16-bit residual rows added before the rounding (may alias C)
     const char* resid; int ldr;
+    // epilogue BIAS_GELU_MIX_T: second stacked operand (rows of the other expert) and the per-token gate pair
+    const char* A2; const float* mix_gates;
 };
 
 // (sum x, sum x^2) of a K-wide row -> (rstd, -mu rstd).  One shared definition with the operations written out (no contraction left

@@ -343,6 +343,36 @@ extern "C" int slime_gate_mix_ex(const float* x, int D, const float* w_gate, con
     return SLIME_OK;
 }
 
+// The gate pair of every row, for the GEMM epilogue that mixes the two experts' hidden rows in registers (SLIME_EPI_BIAS_GELU_MIX_T).
+// The arithmetic is gate_mix_kernel's, instruction for instruction.
+__global__ void __launch_bounds__(256) gate_weights_kernel(const float* x, int D, const float* wg, float* out, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float l0 = 0.f, l1 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xv = xr[c];
+        const float2 w = *reinterpret_cast<const float2*>(wg + 2 * c);
+        l0 += xv * w.x; l1 += xv * w.y;
+    }
+    l0 = wave_sum(l0); l1 = wave_sum(l1);
+    const float m = fmaxf(l0, l1);
+    const float p0 = expf(l0 - m), p1 = expf(l1 - m);
+    const float ps = p0 + p1;
+    const float s0 = p0 / ps, s1 = p1 / ps;            // softmax
+    const float den = s0 + s1 + 1e-6f;                 // top-2-of-2 renormalisation
+    if (lane == 0) *reinterpret_cast<float2*>(out + 2 * (size_t)row) = make_float2(s0 / den, s1 / den);
+}
+
+extern "C" int slime_gate_weights(const float* x, int D, const float* w_gate, float* out, int rows, void* stream) {
+    SLIME_REQUIRE(x && w_gate && out && rows > 0 && D > 0, "gate_weights: bad input");
+    SLIME_REQUIRE(((uintptr_t)out % 8) == 0, "gate_weights: out must be 8-byte aligned");
+    hipLaunchKernelGGL(gate_weights_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, D, w_gate, out, rows);
+    SLIME_CHECK_LAUNCH("gate_weights");
+    return SLIME_OK;
+}
+
 // The same gates applied to the MLP's HIDDEN rows (round 4): the projector's second Linear is linear and g0 + g1 = 1 / (1 + 1e-6), so
 // W2 (g0 a0 + g1 a1) + b2 replaces g0 (W2 a0 + b2) + g1 (W2 a1 + b2) -- the second Linear then runs over ONE row per token instead of
 // two.  a0 / a1 / out: T [rows, H]; out may be a1 (each thread reads its elements before it writes them).  The gate arithmetic is

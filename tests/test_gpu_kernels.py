@@ -245,6 +245,60 @@ def test_gemm_persistent_equals_direct_b(dev, dtype, tile, M, N, epi_name):
     assert torch.equal(outs[tile], outs[12])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(577, 512, 128), (64, 256, 1024), (1153, 4096, 1024), (4608, 4096, 1024)])
+def test_gemm_gelu_mix_epilogue(dev, dtype, M, N, K):
+    """SLIME_EPI_BIAS_GELU_MIX_T (round 4): one direct-B launch computes erf-GELU(A W^T + b) and erf-GELU(A2 W^T + b) for a token and
+    stores T(g0 a0 + g1 a1) -- the GatedBlock's two experts' hidden rows mixed in fp32, rounded once.  Against float64 arithmetic on
+    the same rounded operands; ragged token counts (577, 1153), one tile (64), the adapter's shape (4608 x 4096 x 1024); guard rows
+    past M untouched; and the result equals the two-launch form (BIAS_GELU_T twice + slime_gate_premix) up to ITS extra rounding."""
+    import ctypes as C
+    from slime_amd import ops, _lib
+    lib = _lib.load()
+    code = ops.dtype_code(dtype)
+    a = _rand((M, K), dtype, dev, 41)
+    a2 = _rand((M, K), dtype, dev, 42)
+    w = _rand((N, K), dtype, dev, 43, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 44, 0.5)
+    x = _rand((M, 256), torch.float32, dev, 45)
+    wg = _rand((256, 2), torch.float32, dev, 46, 0.2)
+    gates = torch.empty((M, 2), dtype=torch.float32, device=dev)
+    _lib.check(lib.slime_gate_weights(x.data_ptr(), 256, wg.data_ptr(), gates.data_ptr(), M, ops._stream()), "slime_gate_weights")
+    p = torch.softmax(x.double().cpu() @ wg.double().cpu(), 1)
+    gref = p / (p.sum(1, keepdim=True) + 1e-6)
+    assert float((gates.double().cpu() - gref).abs().max()) < 2e-5
+    wf = ops.pack_b_frag(w)
+    buf = torch.full((M + 70, N), 7.0, dtype=dtype, device=dev)
+    g = _lib.GemmArgs(A=a.data_ptr(), lda=K, B=w.data_ptr(), bias=bias.data_ptr(), C=buf.data_ptr(), ldc=N, M=M, N=N, K=K, dtype=code,
+                      epilogue=_lib.EPI_BIAS_GELU_MIX_T, B_frag=wf.data_ptr(), A2=a2.data_ptr(), mix_gates=gates.data_ptr())
+    _lib.check(lib.slime_gemm_ex(C.byref(g), ops._stream()), "slime_gemm_ex")
+    torch.cuda.synchronize()
+    assert bool((buf[M:] == 7.0).all()), "rows past M were written"
+    wd, bd, gd = w.double().cpu(), bias.double().cpu(), gates.double().cpu()
+    h0 = torch.nn.functional.gelu(a.double().cpu() @ wd.T + bd)
+    h1 = torch.nn.functional.gelu(a2.double().cpu() @ wd.T + bd)
+    want = gd[:, :1] * h0 + gd[:, 1:] * h1
+    got = buf[:M].double().cpu()
+    half = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    mag = (gd[:, :1] * h0).abs() + (gd[:, 1:] * h1).abs()
+    excess = (got - want).abs() - (1.02 * half * want.abs() + 2e-5 * (mag + 1.0) + 1e-7)      # + fp32 accumulation of K products, erff
+    i = int(excess.argmax())
+    assert float(excess.max()) <= 0, (float(excess.max()), float(got.flatten()[i]), float(want.flatten()[i]))
+    # the two-launch form: hidden rows rounded per expert, then mixed and rounded again
+    mid = torch.empty((2 * M, N), dtype=dtype, device=dev)
+    for src, dst in ((a, mid[:M]), (a2, mid[M:])):
+        g2 = _lib.GemmArgs(A=src.data_ptr(), lda=K, B=w.data_ptr(), bias=bias.data_ptr(), C=dst.data_ptr(), ldc=N, M=M, N=N, K=K, dtype=code,
+                           epilogue=_lib.EPI_BIAS_GELU_T, B_frag=wf.data_ptr())
+        _lib.check(lib.slime_gemm_ex(C.byref(g2), ops._stream()), "slime_gemm_ex")
+    _lib.check(lib.slime_gate_premix(x.data_ptr(), 256, wg.data_ptr(), mid[:M].data_ptr(), mid[M:].data_ptr(), mid[M:].data_ptr(), code, M, N,
+                                     ops._stream()), "slime_gate_premix")
+    assert rel_l2(mid[M:].float().cpu(), got.float()) < (4e-3 if dtype == torch.bfloat16 else 5e-4)
+    assert rel_l2(got.float(), want.float()) < (2.5e-3 if dtype == torch.bfloat16 else 3.2e-4)
+    # without the fragment-order weights there is no kernel for this epilogue: loud
+    g.B_frag = None
+    assert lib.slime_gemm_ex(C.byref(g), ops._stream()) != 0
+
+
 def test_gemm_direct_b_determinism_under_load(dev):
     """Counted waits: a load that is waited for too early shows up as run-to-run differences, not as a large error.  The same
     GEMM 20 times while a second stream keeps the memory system busy: every result identical."""
