@@ -442,3 +442,45 @@ def test_attention_partner_redeal_is_a_bijection_and_pairs_share_an_xcd(heads, b
         for (h, b, z), L in seen.items():
             if z + 1 < qsplit:
                 assert seen[(h, b, z + 1)] == L + 8
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """slime_amd/_lib.py mirrors the header's argument structs and enums by hand.  A C program compiled against include/slime_hip.h
+    prints sizeof / offsetof of every struct field and the enum values; the ctypes classes must agree field by field (a field added
+    to one side only, or in another order, would silently shift every later pointer)."""
+    import re
+    import shutil
+    import subprocess
+    from slime_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+    pairs = {"slime_gemm_args": _lib.GemmArgs, "slime_vit_desc": _lib.VitDesc, "slime_resampler_desc": _lib.ResamplerDesc,
+             "slime_mlp_desc": _lib.MlpDesc, "slime_llama_attn_desc": _lib.LlamaAttnDesc, "slime_probe": _lib.Probe}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{_lib.HEADER_PATH}"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        assert re.search(r"}\s*" + cname + r"\s*;", text), cname
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    epi_block = text[text.index("SLIME_EPI_BIAS_T"):]
+    epi_block = epi_block[:epi_block.index("}")]                                  # the epilogue enum's body
+    enums = ["SLIME_BF16", "SLIME_F16", "SLIME_F32", "SLIME_U8", "SLIME_ABI_VERSION"] + list(dict.fromkeys(re.findall(r"SLIME_EPI_[A-Z0-9_]+", epi_block)))
+    for e in enums:
+        lines.append(f'printf("{e} %d\\n", (int){e});')
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), str(src)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == __import__("ctypes").sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert (int(got["SLIME_BF16"]), int(got["SLIME_F16"]), int(got["SLIME_F32"]), int(got["SLIME_U8"])) == (_lib.BF16, _lib.F16, _lib.F32, _lib.U8)
+    assert int(got["SLIME_ABI_VERSION"]) == _lib.ABI_VERSION
+    epi = [e for e in enums if e.startswith("SLIME_EPI_")]
+    assert len(epi) == 8
+    for e in epi:
+        assert int(got[e]) == getattr(_lib, e[len("SLIME_"):]), e
