@@ -2,7 +2,10 @@
 """Contract benchmark: image-crops/sec of the SliME visual hot path (ViT + projector) on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 works both ways: started plainly (`python bench.py --gpus N ...`, no WORLD_SIZE in the environment) the script
+    launches its own N ranks -- it re-runs itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free port>` and passes rank 0's line through --; started under torch.distributed.run
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) it is one of the ranks.
 
 Default (= what the driver runs) is BASELINE.json configs[1] ("config 2"): one STEP = one pass of the hot path over
 8 images x (1 global + 4 local) 336x336 crops = 40 crops per GPU (weak scaling: the global batch is 8*N images), bf16 MFMA
@@ -200,24 +203,57 @@ def parity_vs_oracle(tower_sd, adapter_sd, px, ref, dev, nw, nh):
     return out
 
 
-def pmc_traffic(rocprof_name, required=True):
+def pmc_traffic(rocprof_name, profiled_shape=True):
     """HBM bytes per launch of a kernel from the COMMITTED PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, profiles/README.md).
     It is a profile of this kernel at this shape, not a measurement of this run (PMC counters need rocprofv3 around the process):
-    the bench line says so in `traffic_source`.  A kernel that is missing from the committed summary is an ERROR."""
+    the bench line says so in `traffic_source` and names the commit the passes ran on in `traffic_head`.  Returns
+    (bytes | None, source, head, error | None): a dominant kernel that is missing from the committed summary (another CU count,
+    a changed tile rule or template argument) leaves `traffic` null AND sets `traffic_error` -- the line is still printed, and
+    tests/test_gpu_bench_contract.py asserts that the default line carries no such error."""
     pmc = os.path.join(ROOT, "profiles", PMC_FILE)
-    table = json.load(open(pmc))
+    src = "profiles/" + PMC_FILE
+    try:
+        table = json.load(open(pmc))
+    except (OSError, ValueError) as e:
+        return None, src, None, f"cannot read {src}: {e}"
+    meta = table.get("_meta", {})
+    head = meta.get("git_head")
     rec = table.get(rocprof_name)
     if rec is None:                                       # the summary keys some kernels with their variant / grid ("prefill32_kernel<BF16, 6> [grid 65536]")
         stem = rocprof_name.rstrip(">")
         hits = [k for k in table if k.startswith(stem)]
         rec = table[hits[0]] if len(hits) == 1 else None
     if rec is None or "hbm_read_bytes_corrected" not in rec or "hbm_write_bytes" not in rec:
-        if not required:      # launch shapes tools/pmc_target.py does not profile (config 3's 34-crop halves, rank shards): say so
-            return None, f"not profiled: profiles/{PMC_FILE} holds the default step's launch shapes (20-crop half batches) only"
-        # a renamed / re-dispatched dominant kernel must not silently turn the field into null (VERDICT r3 weak #5)
-        raise SystemExit(f"bench.py: profiles/{PMC_FILE} has no HBM-traffic record for the dominant kernel {rocprof_name!r}: "
-                         "re-run tools/run_pmc.sh + tools/summarize_prof.py and commit the summary")
-    return int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"]), "profiles/" + os.path.basename(pmc)
+        if not profiled_shape:  # launch shapes tools/pmc_target.py does not profile (config 3's 34-crop halves, rank shards): say so
+            return None, f"not profiled: {src} holds the default step's launch shapes (20-crop half batches) only", head, None
+        return None, src, head, (f"{src} has no HBM-traffic record for the dominant kernel {rocprof_name!r}: re-run tools/run_pmc.sh + "
+                                 "tools/summarize_prof.py and commit the summary")
+    return int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"]), src, head, None
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks here (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 and a free port -- the container hostname may not resolve) and hand the
+    children's stdout (rank 0's JSON line) and exit status through.  The reference has no counterpart: its multi-GPU driver is
+    one independent process per GPU (/root/reference/scripts/llama/eval/textvqa.sh:17-26)."""
+    import socket
+    import subprocess
+    single = os.environ.get("SLIME_BENCH_SINGLE_DEVICE") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not single and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node shows {have} GPU(s) (set SLIME_BENCH_SINGLE_DEVICE=1 SLIME_BENCH_BACKEND=gloo "
+                         "to rehearse the multi-process path on one device)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")                # tower side stream + tail stream + RCCL's: see the top of this file
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's hipIpcGetMemHandle fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    env["SLIME_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -232,9 +268,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))             # one rank per GPU, started by this process
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.config == 4 and world > 1:
         raise SystemExit("--config 4 is the single-GPU prefill configuration (BASELINE configs[3]); the sharded one is --config 5")
@@ -290,7 +326,7 @@ def main():
 
     if not strong:
         pixels = W.synthetic_pixels(n_step, seed=100 + rank).to(dev).to(dt)     # resident in HBM before timing
-        cur = {"pixels": pixels, "pg": pg, "post": post, "dt": dt}              # what step() runs on (re-pointed for the fp16 leg)
+        cur = {"pixels": pixels, "pg": pg, "post": post, "dt": dt, "tower": tower}   # what step() runs on (re-pointed for the fp16 leg)
 
         def tail(feats):
             if collective:
@@ -305,7 +341,7 @@ def main():
             return out
 
         def produce():
-            return tower(cur["pixels"])                                          # [40,576,1024] bf16
+            return cur["tower"](cur["pixels"])                                   # [40,576,1024] bf16
         extra_cfg["gather"] = "async all-gather of the rank's bf16 tower features, overlapping the adapter (overhead-only in weak scaling: each rank's adapter reads its own block)" if collective else "none"
     else:
         # strong scaling (config 3): identical crop list on every rank; rank r encodes its block, the exchange reassembles
@@ -389,19 +425,27 @@ def main():
         return dt_s
 
     elapsed = timed_region()
+    rank_ms = [elapsed / args.steps * 1e3]
     if collective:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                            # each rank's own clock around the same K steps
+        rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what the communicator itself says (not the environment): backend name and the number of ranks in it
+        extra_cfg["collective_backend"] = dist.get_backend()
+        extra_cfg["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
+        extra_cfg["launched_by"] = "bench.py self-launch" if os.environ.get("SLIME_BENCH_SELF_LAUNCHED") == "1" else "torch.distributed.run"
 
     if rank == 0:
         crops_total = n_step * (1 if strong else world) * args.steps
         value = crops_total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         step_gf = n_step * GF_VIT_PER_CROP + IMAGES * GF_GLOBAL_PER_IMAGE + IMAGES * LOCAL * GF_LOCAL_PER_CROP
-        step_gf_reference = step_gf + IMAGES * (GF_GLOBAL_PER_IMAGE_REFERENCE - GF_GLOBAL_PER_IMAGE)
         if prefill:
             step_gf += prefill.gflop
+        step_gf_reference = step_gf + IMAGES * (GF_GLOBAL_PER_IMAGE_REFERENCE - GF_GLOBAL_PER_IMAGE)
         path_tflops = step_gf * (1 if strong else world) / (elapsed / args.steps) / 1e3
         halves = 2 if tower.vision_tower.two_streams else 1
         per_rank = -(-n_step // world) if strong else n_step
@@ -413,7 +457,7 @@ def main():
             per.update(pk)
             roof_kernel = pk["prefill_attention"]
         # the driver's line (config 2, 40 crops per GPU) must carry a traffic figure; other launch shapes carry one if profiled
-        traffic, traffic_src = pmc_traffic(roof_kernel["rocprof_name"], required=(args.config == 2 and not strong))
+        traffic, traffic_src, traffic_head, traffic_err = pmc_traffic(roof_kernel["rocprof_name"], profiled_shape=(args.config == 2 and not strong and world == 1))
         workload = {2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
                     3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
                     4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers",
@@ -421,7 +465,8 @@ def main():
         res = {
             "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid" if args.config != 3 else "image-crops/sec (ViT+projector) at 336px, 1+16 grid",
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
+            "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config,
                        "crops_per_gpu": per_rank, "images_per_step": IMAGES * (1 if strong else world), "grid": f"1+{LOCAL}",
@@ -441,7 +486,8 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": f"{roof_kernel['rocprof_name']} ({roof_kernel['label']}, M={roof_kernel['M']} N={roof_kernel['N']} K={roof_kernel['K']})",
                          "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(roof_kernel["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": round(roof_kernel["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head,
+                         **({"traffic_error": traffic_err} if traffic_err else {}),
                          "traffic_algorithmic": roof_kernel.get("algorithmic_bytes"),
                          "launch_ms": roof_kernel["ms"], "launch_ms_min": roof_kernel["min_ms"], "launch_ms_max": roof_kernel.get("max_ms"),
                          "frac_min": round(roof_kernel["gflop_per_launch"] / roof_kernel.get("max_ms", roof_kernel["ms"]) / PEAK_BF16_TFLOPS, 4),
@@ -459,14 +505,20 @@ def main():
             # The SAME step in the reference's inference dtype (fp16: llava/model/builder.py:43) -- the dtype whose projector
             # outputs meet north_star's 1e-3 (parity.fp16 below): same region, same K / W, timed right after the bf16 line.
             f16 = torch.float16
-            tower.vision_tower.to(f16)
-            cur.update(pixels=pixels.to(f16), pg=model.mm_projector.packed(f16), post=model.sampler.post_qformer.packed(576, f16), dt=f16)
+            # a second encoder loaded from the fp32 state dicts (NOT the bf16 module cast to fp16 and back: lossy outside fp16's range)
+            enc16 = SlimeVisualEncoder(default_slime_config("synthetic:1234"))
+            enc16.load_visual_state(tower_sd, adapter_sd)
+            enc16.to(dev)
+            enc16.get_vision_tower().vision_tower.to(f16)
+            tower16, model16 = enc16.get_vision_tower(), enc16.get_model()
+            cur.update(pixels=pixels.to(f16), pg=model16.mm_projector.packed(f16), post=model16.sampler.post_qformer.packed(576, f16), dt=f16,
+                       tower=tower16)
             e16 = timed_region()
             res["fp16"] = {"ms_per_step": round(e16 / args.steps * 1e3, 3), "value": round(n_step * args.steps / e16, 1), "unit": "crops/s",
                            "vs_bf16": round(elapsed / e16, 4),
                            "note": "same step, same timed region, fp16 MFMA operands (the reference's inference dtype; meets the 1e-3 target, see parity.fp16)"}
-            tower.vision_tower.to(dt)
-            cur.update(pixels=pixels, pg=pg, post=post, dt=dt)
+            cur.update(pixels=pixels, pg=pg, post=post, dt=dt, tower=tower)
+            del enc16, tower16, model16
         if world == 1 and args.config == 2 and not args.no_cpu_baseline:
             res["cpu_baseline"], px_s, ref_s = cpu_baseline(tower_sd, adapter_sd, CPI)
             res["parity"] = parity_vs_oracle(tower_sd, adapter_sd, px_s, ref_s, dev, NW, NH)

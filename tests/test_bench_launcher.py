@@ -1,0 +1,73 @@
+"""bench.py's own rank launcher (CPU part): `python bench.py --gpus N` with no rank environment re-runs the script under
+torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 -- checked here on the command / environment it builds;
+tests/test_gpu_bench_contract.py runs it for real on the GPU box."""
+import importlib.util
+import os
+import subprocess
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_bench():
+    spec = importlib.util.spec_from_file_location("slime_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_self_launch_builds_one_rank_per_gpu(monkeypatch):
+    bench = _load_bench()
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("SLIME_BENCH_SINGLE_DEVICE", "1")
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.self_launch(4) == 7                           # the children's exit status is handed through
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]      # the ranks get the caller's arguments unchanged
+    assert env["GPU_MAX_HW_QUEUES"] == "8" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["SLIME_BENCH_SELF_LAUNCHED"] == "1"
+
+
+def test_self_launch_refuses_without_enough_gpus(monkeypatch):
+    bench = _load_bench()
+    monkeypatch.delenv("SLIME_BENCH_SINGLE_DEVICE", raising=False)
+    import torch
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch(torch.cuda.device_count() + 1)
+    assert "GPU(s)" in str(e.value)
+
+
+def test_main_self_launches_only_without_a_rank_environment(monkeypatch):
+    bench = _load_bench()
+    calls = []
+    monkeypatch.setattr(bench, "self_launch", lambda n: calls.append(n) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert calls == [2] and e.value.code == 0
+    # under torch.distributed.run (WORLD_SIZE set) the script is a rank: a mismatch is an error, not another launch
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert calls == [2] and "WORLD_SIZE=4" in str(e.value)
+
+
+def test_pmc_traffic_reports_a_missing_kernel_without_aborting():
+    bench = _load_bench()
+    t, src, head, err = bench.pmc_traffic("no_such_kernel<BF16>")
+    assert t is None and src.startswith("profiles/") and err and "no_such_kernel" in err
+    t, src, head, err = bench.pmc_traffic("no_such_kernel<BF16>", profiled_shape=False)
+    assert t is None and err is None and src.startswith("not profiled")

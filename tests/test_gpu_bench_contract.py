@@ -38,3 +38,62 @@ def test_bench_prints_one_contract_line():
     assert max(d["parity"]["fp16"]["rel_l2_global"], d["parity"]["fp16"]["rel_l2_local"]) <= 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "crops/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
+    assert "traffic_error" not in r, r.get("traffic_error")       # the committed PMC summary knows the dominant kernel of this build
+    assert d["ms_per_step_rank_min"] <= d["ms_per_step"] + 1e-3 and d["ms_per_step_rank_max"] >= d["ms_per_step_rank_min"]
+
+
+def _bench(args, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                                            # the driver's plain `python bench.py ...` environment
+    e.update(env or {})
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=timeout, cwd=ROOT, env=e)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+ONE_GPU_REHEARSAL = {"SLIME_BENCH_SINGLE_DEVICE": "1", "SLIME_BENCH_BACKEND": "gloo"}
+
+
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it (no torch.distributed.run around it, no rank environment):
+    the script starts its two ranks itself.  One GPU here, so both ranks sit on cuda:0 and the collective backend is gloo (RCCL
+    refuses two ranks on one device) -- the numbers mean nothing, the launch / rendezvous / gather / max-reduce / rank-0 line do."""
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], ONE_GPU_REHEARSAL)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["launched_by"] == "bench.py self-launch" and d["config"]["collective_backend"] == "gloo"
+    assert d["config"]["rccl_ranks"] is None                      # gloo rehearsal: no RCCL communicator to report
+    assert d["config"]["crops_per_gpu"] == 40 and d["config"]["images_per_step"] == 16
+    assert abs(d["value"] - 80 * 1e3 / d["ms_per_step"]) / d["value"] < 0.01          # whole-job rate: 2 x 40 crops per step
+    assert d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"] and abs(d["ms_per_step_rank_max"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SLIME_BENCH_SINGLE_DEVICE")}
+    import torch
+    n = torch.cuda.device_count() + 1
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=e)
+    assert res.returncode != 0 and "GPU(s)" in res.stderr and not res.stdout.strip()
+
+
+@pytest.mark.parametrize("config,extra", [(3, []), (4, []), (5, []), (3, ["--gpus", "2"]), (5, ["--gpus", "2"])])
+def test_bench_other_configs_print_their_line(config, extra):
+    """BASELINE configs 3 / 4 / 5 through bench.py, 2 steps each (and the strong-scaling ones once more as a self-launched 2-rank
+    rehearsal on the one GPU): those modes are not what the driver runs, so nothing else would notice them rotting."""
+    d = _bench(["--config", str(config), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, ONE_GPU_REHEARSAL if extra else None)
+    world = 2 if extra else 1
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["config"]["baseline_config"] == config
+    assert d["scaling"] == {3: "strong", 4: "weak", 5: "strong"}[config]
+    crops = {3: 68, 4: 40, 5: 40}[config]
+    assert abs(d["value"] - crops * 1e3 / d["ms_per_step"]) / d["value"] < 0.01      # strong scaling / one GPU: the step's crops, once
+    assert d["config"]["crops_per_gpu"] == -(-crops // world) if config != 4 else d["config"]["crops_per_gpu"] == 40
+    r = d["roofline"]
+    assert 0.02 < r["frac"] < 1.0 and r["achieved"] > 0 and "traffic_error" not in r
+    if config in (4, 5):
+        assert d["config"]["prefill_seq_len"] == {4: 1216, 5: 9280}[config] and d["config"]["llama_layers"] == 32
+        assert "prefill32_kernel" in r["kernel"]
+        assert d["path_mfma"]["gflop_per_step_reference_arithmetic"] > d["path_mfma"]["gflop_per_step"] > d["config"]["prefill_gflop_per_step"]
