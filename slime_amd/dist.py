@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import json
 import os
+import re
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -55,12 +56,35 @@ def tower_latency_profile(path: Optional[str] = None) -> dict:
     return _profile_cache[path]
 
 
+_DTYPE_KEYS = {"bf16": "bf16", "bfloat16": "bf16", "torch.bfloat16": "bf16", "fp16": "fp16", "f16": "fp16", "half": "fp16", "float16": "fp16",
+               "torch.float16": "fp16", "fp32": "fp32", "f32": "fp32", "float": "fp32", "float32": "fp32", "torch.float32": "fp32"}
+
+
+def _dtype_key(x) -> str:
+    k = str(x).strip().lower()
+    return _DTYPE_KEYS.get(k, k)
+
+
+def _device_key(x) -> str:
+    """'AMD Instinct MI355X' / 'MI355X' -> 'mi355x' (the part number is the key; an unrecognised name is compared whole)."""
+    m = re.search(r"\bmi\d+[a-z]*\b", str(x).lower())
+    return m.group(0) if m else str(x).strip().lower()
+
+
+def _model_key(x) -> str:
+    """'CLIP-ViT-L/14-336 (23 live layers)' -> 'clip-vit-l/14-336': the first token names the tower, the rest is commentary."""
+    parts = str(x).strip().lower().split()
+    return parts[0] if parts else ""
+
+
 def profile_applies(profile: dict, device_name: Optional[str] = None, model: Optional[str] = None, dtype: Optional[str] = None) -> bool:
-    """Does the profile describe the configuration that is running?  Unknown (None) fields are not held against it."""
-    def ok(want, have):
-        return have is None or want is None or str(want).lower().replace(" ", "") in str(have).lower().replace(" ", "") \
-            or str(have).lower().replace(" ", "") in str(want).lower().replace(" ", "")
-    return ok(profile.get("device"), device_name) and ok(profile.get("model"), model) and ok(profile.get("dtype"), dtype)
+    """Does the profile describe the configuration that is running?  Unknown (None) fields are not held against it; known ones
+    are compared for EQUALITY on a canonical key (part number, tower name, bf16 / fp16 / fp32) -- a substring test would let
+    'float16' pass for 'bfloat16' and 'MI35' for 'MI355X'."""
+    def ok(want, have, key):
+        return have is None or want is None or key(want) == key(have)
+    return ok(profile.get("device"), device_name, _device_key) and ok(profile.get("model"), model, _model_key) \
+        and ok(profile.get("dtype"), dtype, _dtype_key)
 
 
 def calibrate_tower_latency(tower_fn: Callable[[torch.Tensor], torch.Tensor], make_crops: Callable[[int], torch.Tensor],

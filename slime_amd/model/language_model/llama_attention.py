@@ -82,7 +82,8 @@ def _self_attn_return_arity(M) -> int:
     import re
     try:
         src = inspect.getsource(M.LlamaDecoderLayer.forward)
-        m = re.search(r"([\w\s,]+?)=\s*self\.self_attn\(", src)
+        # the assignment targets on the ONE line that calls self.self_attn( -- anchored so that nothing above it can join the match
+        m = re.search(r"^[ \t]*([^\n=]+?)=[ \t]*self\.self_attn\(", src, re.M)
         if m:
             return len([t for t in m.group(1).split(",") if t.strip()])
     except (OSError, TypeError):
@@ -110,14 +111,23 @@ def replace_llama_attn_with_hip_attn():
     import transformers
     from transformers.models.llama import modeling_llama as M
     arity = _self_attn_return_arity(M)
+    import inspect
+    stock = _PATCH_STATE.get("forward", M.LlamaAttention.forward)
+    # positional parameters of the INSTALLED LlamaAttention.forward after hidden_states: (attention_mask, position_ids, past_key_value,
+    # ...) up to 4.47, (position_embeddings, attention_mask, past_key_value(s), cache_position) from 4.48 on -- extras are mapped by name
+    positional = [n for n, q in list(inspect.signature(stock).parameters.items())[2:]
+                  if q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD)]
 
-    def forward(self, hidden_states, *args, attention_mask=None, position_ids=None, past_key_value=None, past_key_values=None,
-                output_attentions=False, use_cache=False, **kw):
-        # positional forms of the old signature (hidden_states, attention_mask, position_ids, past_key_value, ...)
-        if len(args) > 0 and attention_mask is None and not isinstance(args[0], tuple):
-            attention_mask = args[0]
-        if len(args) > 1 and position_ids is None:
-            position_ids = args[1]
+    def forward(self, hidden_states, *args, **kw):
+        if len(args) > len(positional):
+            raise TypeError(f"LlamaAttention.forward takes at most {len(positional) + 1} positional arguments ({len(args) + 1} given)")
+        for name, value in zip(positional, args):
+            if name in kw:
+                raise TypeError(f"LlamaAttention.forward got multiple values for argument {name!r}")
+            kw[name] = value
+        attention_mask, position_ids = kw.get("attention_mask"), kw.get("position_ids")
+        past_key_value, past_key_values = kw.get("past_key_value"), kw.get("past_key_values")
+        output_attentions, use_cache = kw.get("output_attentions", False), kw.get("use_cache", False)
         # prefill only: HF generate() defaults to use_cache=True -- call the patched model with use_cache=False (a present
         # k/v return for the prefill step would be the natural extension; decode is outside SURVEY section 8)
         if past_key_value is not None or past_key_values is not None or use_cache:

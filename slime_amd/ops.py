@@ -6,6 +6,7 @@ library is absent).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import math
 import threading
@@ -769,7 +770,13 @@ class PackedLlamaAttention:
         return _llama_workspace()
 
 
-_LLAMA_WS: Dict[tuple, Workspace] = {}
+# One grow-only Workspace per (device, stream) for the Llama attention sub-layer: ~200 MB at SliME-8B prefill shapes (8 x 1216 tokens).
+# Bounded: at most LLAMA_WS_MAX_STREAMS entries, least recently used evicted (a server that prefills on many torch streams would
+# otherwise pin that much per stream handle forever -- the pool has ~32 handles per device); ``release_llama_workspaces()`` drops all.
+# An evicted buffer goes back to the caching allocator, which keeps it stream-ordered for the stream it was allocated on; work
+# already enqueued on ANOTHER stream that used it is protected by ``record_stream`` below.
+LLAMA_WS_MAX_STREAMS = 4
+_LLAMA_WS: "collections.OrderedDict[tuple, Workspace]" = collections.OrderedDict()
 _LLAMA_WS_LOCK = threading.Lock()
 
 
@@ -780,7 +787,20 @@ def _llama_workspace() -> Workspace:
         ws = _LLAMA_WS.get(key)
         if ws is None:
             ws = _LLAMA_WS[key] = Workspace()
+        _LLAMA_WS.move_to_end(key)
+        while len(_LLAMA_WS) > LLAMA_WS_MAX_STREAMS:
+            _, old = _LLAMA_WS.popitem(last=False)
+            if old.buf is not None:
+                old.buf.record_stream(st)               # never handed to a new owner before this stream's queued work is done
         return ws
+
+
+def release_llama_workspaces() -> int:
+    """Drop every cached Llama-attention workspace (returns the number of bytes released to the caching allocator)."""
+    with _LLAMA_WS_LOCK:
+        n = sum(w.buf.numel() for w in _LLAMA_WS.values() if w.buf is not None)
+        _LLAMA_WS.clear()
+    return n
 
 
 def llama_inv_freq(head_dim: int, theta: float) -> torch.Tensor:

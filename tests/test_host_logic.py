@@ -281,6 +281,18 @@ def test_hf_attention_patch_plumbing_under_installed_transformers(monkeypatch):
             model(inputs_embeds=emb, attention_mask=None, use_cache=False)
         with pytest.raises(NotImplementedError, match="use_cache=False"):
             model(inputs_embeds=emb, attention_mask=mask, use_cache=True)
+        # positional extras are mapped by the INSTALLED signature (4.48+: hidden_states, position_embeddings, attention_mask;
+        # before: hidden_states, attention_mask, position_ids) -- the mask must be recognised as the mask wherever it sits
+        import inspect
+        names = list(inspect.signature(stock).parameters)[2:]
+        vals = {"attention_mask": mask, "position_ids": torch.arange(10)[None], "position_embeddings": (torch.zeros(1), torch.zeros(1))}
+        n_pos = max(i for i, n in enumerate(names) if n in ("attention_mask", "position_ids")) + 1
+        before = len(seen)
+        with torch.no_grad():
+            model.layers[0].self_attn(emb, *[vals.get(n) for n in names[:n_pos]])
+        assert len(seen) == before + 1 and seen[-1][0] == (2, 10) and seen[-1][1] in (None, (1, 10))
+        with pytest.raises(TypeError, match="positional"):
+            model.layers[0].self_attn(emb, *([None] * (len(names) + 1)))
     finally:
         L.restore_llama_attn()
     assert out.shape == (2, 10, 512) and torch.isfinite(out).all()
@@ -306,6 +318,11 @@ def test_gather_chunk_cost_model():
     # the curve is a profile of ONE device / tower / dtype; for anything else the policy decides nothing (chunk 0)
     assert D.profile_applies(prof, "AMD Instinct MI355X", "CLIP-ViT-L/14-336", "bf16") and D.profile_applies(prof)
     assert not D.profile_applies(prof, "AMD Instinct MI300X") and not D.profile_applies(prof, None, None, "fp16")
+    # equality on canonical keys, not substrings -- 'float16' is not 'bfloat16', 'MI35' is not 'MI355X'
+    assert not D.profile_applies(prof, None, None, "float16") and not D.profile_applies(prof, None, None, "f16")
+    assert D.profile_applies(prof, None, None, "torch.bfloat16") and D.profile_applies(prof, None, None, "bfloat16")
+    assert not D.profile_applies(prof, "MI35") and not D.profile_applies(prof, "AMD Instinct MI355") and D.profile_applies(prof, "mi355x")
+    assert not D.profile_applies(prof, None, "CLIP-ViT-L/14") and D.profile_applies(prof, None, "clip-vit-l/14-336 (fp16 run)")
     assert D.choose_chunk(400, 8) > 0 and D.choose_chunk(400, 8, device_name="AMD Instinct MI300X") == 0
     flat = {"device": "MI355X", "model": None, "dtype": None, "ms": {1: 0.1, 100: 10.0}, "ms_per_crop_beyond": 0.1}
     assert D.choose_chunk(34, 8, profile=flat) > 0                        # no per-pass floor in this curve: micro-batches pay early
