@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 4
+#define SLIME_ABI_VERSION 5
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 
@@ -49,7 +49,10 @@ enum {
     SLIME_EPI_BIAS_RESID_F32,    /* C(fp32) += A*B^T + bias, in place       (out_proj / fc2 + residual)  */
     SLIME_EPI_BIAS_RESID_F32_LN, /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
     SLIME_EPI_BIAS_RESID_T,      /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
-    SLIME_EPI_BIAS_GELU_MIX_T    /* C[t] = T(g0[t] gelu(A[t] B^T + bias) + g1[t] gelu(A2[t] B^T + bias)): GatedBlock hidden rows, mixed in fp32 (slime_gemm_ex) */
+    SLIME_EPI_BIAS_GELU_MIX_T,   /* C[t] = T(g0[t] gelu(A[t] B^T + bias) + g1[t] gelu(A2[t] B^T + bias)): GatedBlock hidden rows, mixed in fp32 (slime_gemm_ex) */
+    SLIME_EPI_BIAS_RESID_SPLIT_LN /* the residual update of BIAS_RESID_F32_LN on a 2 x 16-bit SPLIT residual stream (ABI 5, slime_gemm_ex):
+                                   * h = float(C) + float(lo16); c = A*B^T + bias + h; C = T(c), lo16 = T(c - float(C)); stats_out as _LN.
+                                   * C is at once the upper half of the stream and the next GEMM's operand (no separate x16 copy). */
 };
 
 int slime_abi_version(void);
@@ -82,6 +85,7 @@ typedef struct {
     const void* resid; int ldr;  /* epilogue BIAS_RESID_T: residual rows T [M, ldr] (may alias C), else NULL / 0     */
     const void* A2;              /* epilogue BIAS_GELU_MIX_T: the second expert's operand rows T [M, lda], else NULL  */
     const float* mix_gates;      /* epilogue BIAS_GELU_MIX_T: fp32 [M, 2] gate pair per row (slime_gate_weights)      */
+    void* lo16; int ldlo;        /* epilogue BIAS_RESID_SPLIT_LN: lower half of the split residual stream, T [M, ldlo], read and written in place */
 } slime_gemm_args;
 int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 /* Epilogue SLIME_EPI_BIAS_GELU_MIX_T (round 4; needs B_frag, N % 256 == 0): ONE launch computes projection[0] + GELU of BOTH experts'
@@ -97,6 +101,11 @@ int slime_gemm_ex(const slime_gemm_args* args, void* stream);
  * N % 64 == 0, K % 64 == 0, out = slime_gemm_packed_b_bytes(N, K) bytes, out != B.  No reference counterpart (layout only). */
 size_t slime_gemm_packed_b_bytes(int N, int K);
 int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* stream);
+/* ABI 5: every kernel slime_gemm_ex dispatches to can take the static operand from the fragment-order image ALONE (the LDS-staged
+ * kernels fetch the same 16-byte chunks from it through permuted per-lane source addresses: bit-identical results), so a caller
+ * that packed a weight may pass args.B = NULL and free the row-major copy.  Returns 1 if that holds for an [N, K] operand
+ * (N % 64 == 0, K % 64 == 0), else 0 (then B is required and B_frag is ignored).  Host-only query. */
+int slime_gemm_b_frag_usable(int N, int K);
 
 /* Name (as rocprofv3 prints it) of the kernel instantiation slime_gemm launches for this shape: host-only query. */
 int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, int has_b_frag, char* out_host, size_t out_len);
@@ -111,19 +120,22 @@ int slime_layernorm(const float* x, int ldx, int rows, int D, const float* w, co
                     int normalize, float* out_f32, void* out_t, void* out_t2, const float* add,
                     int add_period, int dtype, void* stream);
 
-/* im2col for the patch-embed conv: pixels [n,3,image,image] (pix_dtype BF16/F16/F32), rounded to T
- * first as `images.to(dtype=self.dtype)` does (clip_encoder.py:55), -> T [n*g*g, kpad], column order
- * (c, ky, kx) as Conv2d weight.flatten(1) (HF :148-154,209-210); columns >= 3*p*p are zero. */
-int slime_im2col(const void* pixels, int pix_dtype, void* out, int n, int image, int patch, int kpad,
-                 int dtype, void* stream);
-
-/* h[n, 1+P, D] = pre_layrnorm( cat(class_embedding, patch_out[n, P, D]) + position_embedding )
- * (HF CLIPVisionEmbeddings.forward :212-217 + pre_layrnorm :642).  fp32 in/out.  If x16 / stats are non-NULL it also
- * prepares the first folded LayerNorm of the layer stack (slime_gemm_ex): x16 T [n*(1+P), D] = T(h) and
- * stats [n*(1+P), D/64, 2] = (sum, sum of squares) of the rounded rows per 64-column group. */
-int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
-                        const float* ln_b, float eps, float* h, void* x16, float* stats, int dtype, int n, int P, int D,
-                        void* stream);
+/* The tower's front end in ONE launch (ABI 5; replaces slime_im2col + patch GEMM + slime_embed_prenorm):
+ *   h[n, 1+P, D] = pre_layrnorm( cat(class_embedding, conv_{patch x patch, stride patch}(pixels)) + position_embedding )
+ * (HF CLIPVisionEmbeddings.forward modeling_clip.py:148-154, 209-217 + pre_layrnorm :642, via clip_encoder.py:51,55).
+ * pixels [n,3,image,image] (pix_dtype F32, or T = dtype: rounded to T first as `images.to(dtype=self.dtype)` does);
+ * patch_w_frag = slime_gemm_pack_b of the conv weight T [D, kpad] (column order (c, ky, kx) = Conv2d.weight.flatten(1), zero
+ * padded to kpad, a multiple of 64); cls f32 [D], pos f32 [1+P, D], ln_w / ln_b f32 [D].  A workgroup stages whole image rows
+ * in LDS with coalesced 16-byte loads, re-tiles the patch x patch tiles into the MFMA operand there, multiplies, and
+ * normalises its rows in registers.  Outputs (any may be NULL except that one of h / x16 is required):
+ *   h     f32 [n*(1+P), D]      the residual stream;
+ *   x16   T   [n*(1+P), D]      T(h) -- the first GEMM's operand and the upper half of the split residual stream;
+ *   lo16  T   [n*(1+P), D]      T(h - float(x16)), the lower half (SLIME_EPI_BIAS_RESID_SPLIT_LN);
+ *   stats f32 [n*(1+P), D/64, 2] (sum, sum of squares) of the ROUNDED rows per 64-column group (first folded LayerNorm).
+ * D in {128, 256, 1024}; image / patch <= 24 patches per side. */
+int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, const void* patch_w_frag, const float* cls, const float* pos,
+                              const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo16, float* stats,
+                              int dtype, int n, int image, int patch, int kpad, int D, void* stream);
 
 /* Fused multi-head attention, softmax(Q K^T) V with fp32 online softmax; Q is expected PRE-SCALED
  * by head_dim^-0.5 * log2(e) (SLIME_ATTN_Q_PRESCALE, folded into the q projection weights and bias at pack
@@ -158,6 +170,9 @@ int slime_gate_weights(const float* x, int D, const float* w_gate /* [D,2] */, f
  * clip_encoder.py:38-39, and output-dtype casts :52,56.) */
 int slime_gather_rows(const float* in, int rows_in, int row_off, void* out, int out_dtype,
                       int groups, int rows_out, int C, void* stream);
+/* The same from a 2 x 16-bit split residual stream (ABI 5): in = float(hi) + float(lo), hi / lo T [groups*rows_in, C]. */
+int slime_gather_rows_split(const void* hi, const void* lo, int dtype, int rows_in, int row_off, void* out, int out_dtype,
+                            int groups, int rows_out, int C, void* stream);
 
 /* Spatial merge of compressed local tokens (llava_arch.py:235-244): in fp32 [n=nh*nw, g*g, C] ->
  * out[dst_row0 + ((gy*g+qy)*nw + gx)*g + qx, :]; merge == 0 is the 'flat' order (:233-234). */
@@ -253,7 +268,7 @@ typedef struct {
     int image, patch, kpad;                 /* kpad = 3*patch*patch rounded up to a multiple of 64       */
     int dtype;                              /* SLIME_BF16 / SLIME_F16                                    */
     float eps;
-    const void*  patch_w;                   /* T   [hidden, kpad]  (zero padded)                          */
+    const void*  patch_w;                   /* T   [hidden, kpad]  (zero padded); unused since ABI 5 (may be NULL): the front end reads patch_w_frag */
     const float* cls;                       /* f32 [hidden]                                               */
     const float* pos;                       /* f32 [1+P, hidden]                                          */
     const float* pre_ln_w; const float* pre_ln_b;
@@ -268,12 +283,16 @@ typedef struct {
     const float* b_fc1;                     /* f32 [L, inter] = b + W1 ln2_b                                              */
     const float* colsum_fc1;                /* f32 [L, inter]                                                             */
     const void*  w_fc2; const float* b_fc2; /* T   [L, hidden, inter];  f32 [L, hidden]                                   */
-    /* optional fragment-order copies of the four per-layer weights (slime_gemm_pack_b per layer, same layer stride), or NULL */
+    /* fragment-order copies of the four per-layer weights (slime_gemm_pack_b per layer, same layer stride), or NULL.  ABI 5: where
+     * a _frag copy is given the row-major tensor of the same weight may be NULL (slime_gemm_b_frag_usable) */
     const void*  w_qkv_frag; const void* w_o_frag; const void* w_fc1_frag; const void* w_fc2_frag;
-    const void*  patch_w_frag;              /* the same for patch_w [hidden, kpad], or NULL                                   */
+    const void*  patch_w_frag;              /* slime_gemm_pack_b of patch_w [hidden, kpad]: REQUIRED since ABI 5 (slime_patch_embed_prenorm) */
 } slime_vit_desc;
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
+/* The epilogue (SLIME_EPI_*) of the tower's out_proj / fc2 launches in this build: SLIME_EPI_BIAS_RESID_SPLIT_LN (2 x 16-bit split
+ * residual stream, ABI 5) -- what a profiler label for those kernels has to be generated with (slime_gemm_kernel_name).  Host-only. */
+int slime_vit_residual_epilogue(void);
 
 /* Optional in-situ timing probe: slime_vit_forward_ex records the HIP events `start` / `stop` (hipEvent_t,
  * owned by the caller) immediately before / after the launch of one kernel of one layer, on the call's

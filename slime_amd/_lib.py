@@ -17,15 +17,17 @@ import re
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslime_hip.so")
+# SLIME_HIP_LIBRARY: run against another build of the SAME ABI (tools/build_variants.sh A/B libraries); there is still no fallback --
+# a missing file raises in load()
+LIB_PATH = os.environ.get("SLIME_HIP_LIBRARY") or os.path.join(_HERE, "libslime_hip.so")
 DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 BF16, F16, F32, U8 = 0, 1, 2, 3
 (EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T,
- EPI_BIAS_GELU_MIX_T) = range(8)
+ EPI_BIAS_GELU_MIX_T, EPI_BIAS_RESID_SPLIT_LN) = range(9)
 
 c_void_p, c_int, c_long, c_float, c_size_t = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
 
@@ -46,7 +48,7 @@ class GemmArgs(C.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
                 ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int),
-                ("A2", c_void_p), ("mix_gates", c_void_p)]
+                ("A2", c_void_p), ("mix_gates", c_void_p), ("lo16", c_void_p), ("ldlo", c_int)]
 
 
 class ResamplerDesc(C.Structure):
@@ -82,14 +84,15 @@ _SIGNATURES = {
     "slime_gemm_pack_b": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "slime_layernorm": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "slime_im2col": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_gemm_b_frag_usable": (c_int, [c_int, c_int]),
+    "slime_patch_embed_prenorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "slime_gemm_ex": (c_int, [_P(GemmArgs), c_void_p]),
-    "slime_embed_prenorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                    c_int, c_int, c_void_p]),
     "slime_attention": (c_int, [c_void_p, c_long, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
                                 c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "slime_gate_mix": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "slime_gather_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "slime_gather_rows_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "slime_merge_rows": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "slime_resample_ksize": (c_int, [c_int, c_int]),
     "slime_resample_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p]),
@@ -114,6 +117,7 @@ _SIGNATURES = {
                                             c_void_p, c_void_p]),
     "slime_router_select_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "slime_vit_workspace_bytes": (c_size_t, [_P(VitDesc), c_int]),
+    "slime_vit_residual_epilogue": (c_int, []),
     "slime_vit_forward": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "slime_vit_forward_ex": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

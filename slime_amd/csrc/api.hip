@@ -54,36 +54,39 @@ static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
 #ifndef SLIME_OPT_ALIAS_WS
 #define SLIME_OPT_ALIAS_WS 1
 #endif
+// Round 5: the residual stream between the layers is a 2 x 16-bit SPLIT (hi = T(h), which IS the next GEMM's operand, lo = T(h - hi))
+// instead of fp32 rows plus a separate T(h) copy: the out_proj / fc2 epilogues move 8 bytes per element instead of 10
+// (SLIME_EPI_BIAS_RESID_SPLIT_LN).  0 = the fp32 stream of rounds 1-4 (tools/build_variants.sh A/B).
+#ifndef SLIME_OPT_SPLIT_RESID
+#define SLIME_OPT_SPLIT_RESID 1
+#endif
 struct VitPlan {
-    size_t xn, qkv, ctx, ff, h, stats, total;   // offsets
+    size_t xn, qkv, ctx, ff, h, stats, total;   // offsets (h: the fp32 residual rows, or the lower half of the split stream)
 };
 
 static VitPlan vit_plan(const slime_vit_desc* d, int n) {
     const int g = d->image / d->patch, P = g * g, S = P + 1;
-    const size_t M = (size_t)n * S, Mp = (size_t)n * P, D = d->hidden;
+    const size_t M = (size_t)n * S, D = d->hidden;
     VitPlan p{};
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
-    p.h = take(M * D * 4);
+    p.h = take(M * D * (SLIME_OPT_SPLIT_RESID ? 2 : 4));
     p.xn = take(M * D * 2);
-    // ff also hosts the patch-embed staging (im2col operand + fp32 conv output) before the layers
     const size_t ff_bytes = M * (size_t)d->inter * 2;
-    const size_t pe_bytes = align_up(Mp * (size_t)d->kpad * 2, 256) + Mp * D * 4;
 #if SLIME_OPT_ALIAS_WS
     // q/k/v and the attention context die before fc1 writes the MLP's intermediate rows, and those die before the next layer's q/k/v
     // GEMM: the three share one region (for CLIP-L, 3 D + D = the intermediate width exactly).  The launches of a stream are serial, so
     // nothing else changes -- except that a 20-crop stream now cycles through 165 MB instead of 260, and the 256 MiB memory-side
-    // cache, which two such streams share, keeps more of what the next kernel reads (profiles/r04_fabric_traffic.txt, section 6).
+    // cache, which two such streams share, keeps more of what the next kernel reads (profiles/r04_fabric_traffic.txt).
     const size_t qkv_bytes = align_up(M * 3 * D * 2, 256), attn_bytes = qkv_bytes + M * D * 2;
-    size_t region = ff_bytes > pe_bytes ? ff_bytes : pe_bytes;
-    if (attn_bytes > region) region = attn_bytes;
+    const size_t region = ff_bytes > attn_bytes ? ff_bytes : attn_bytes;
     p.ff = take(region);
     p.qkv = p.ff;
     p.ctx = p.ff + qkv_bytes;
 #else
     p.qkv = take(M * 3 * D * 2);
     p.ctx = take(M * D * 2);
-    p.ff = take(ff_bytes > pe_bytes ? ff_bytes : pe_bytes);
+    p.ff = take(ff_bytes);
 #endif
     p.stats = take(M * (D / 64) * 2 * sizeof(float));      // LayerNorm fold: (sum, sum of squares) per row and 64-column group
     p.total = align_up(off, 256);
@@ -100,10 +103,17 @@ static int vit_validate(const slime_vit_desc* d) {
     SLIME_REQUIRE(d->image % d->patch == 0, "vit: image %d not a multiple of patch %d", d->image, d->patch);
     SLIME_REQUIRE(d->kpad % 64 == 0 && d->kpad >= 3 * d->patch * d->patch, "vit: kpad=%d", d->kpad);
     SLIME_REQUIRE(d->layers_run >= 0, "vit: layers_run < 0");
-    SLIME_REQUIRE(d->patch_w && d->cls && d->pos && d->pre_ln_w && d->pre_ln_b, "vit: missing embedding weights");
-    SLIME_REQUIRE(d->layers_run == 0 || (d->w_qkv && d->b_qkv && d->colsum_qkv && d->w_o && d->b_o && d->w_fc1 && d->b_fc1 &&
-                                         d->colsum_fc1 && d->w_fc2 && d->b_fc2), "vit: missing layer weights");
+    SLIME_REQUIRE(d->patch_w_frag && d->cls && d->pos && d->pre_ln_w && d->pre_ln_b,
+                  "vit: missing embedding weights (patch_w_frag = slime_gemm_pack_b of the conv weight is required since ABI 5)");
+    // a per-layer weight is given as its fragment-order image, its row-major image, or both (slime_gemm_b_frag_usable)
+    SLIME_REQUIRE(d->layers_run == 0 || ((d->w_qkv || d->w_qkv_frag) && d->b_qkv && d->colsum_qkv && (d->w_o || d->w_o_frag) && d->b_o &&
+                                         (d->w_fc1 || d->w_fc1_frag) && d->b_fc1 && d->colsum_fc1 && (d->w_fc2 || d->w_fc2_frag) && d->b_fc2),
+                  "vit: missing layer weights");
     return SLIME_OK;
+}
+
+extern "C" int slime_vit_residual_epilogue(void) {
+    return SLIME_OPT_SPLIT_RESID ? SLIME_EPI_BIAS_RESID_SPLIT_LN : SLIME_EPI_BIAS_RESID_F32_LN;
 }
 
 extern "C" size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops) {
@@ -161,32 +171,38 @@ static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, i
         return SLIME_EWORKSPACE;
     }
     const int g = d->image / d->patch, P = g * g, S = P + 1, D = d->hidden, F = d->inter;
-    const int M = n * S, Mp = n * P;
+    const int M = n * S;
     char* w = (char*)ws;
-    float* h = hidden_f32 ? hidden_f32 : (float*)(w + p.h);
     void* xn = w + p.xn;
     char* qkv = w + p.qkv;
     void* ctx = w + p.ctx;
     void* ff = w + p.ff;
-    void* a_pe = ff;
-    float* pe_out = (float*)((char*)ff + align_up((size_t)Mp * d->kpad * 2, 256));
     const int dt = d->dtype;
-
     float* stats = (float*)(w + p.stats);
     const int G = D / 64;
+#if SLIME_OPT_SPLIT_RESID
+    // residual stream = (xn, lo): xn = T(h) is the upper half AND the operand of the q/k/v / fc1 GEMMs, lo = T(h - xn)
+    void* lo = w + p.h;
+    float* h = nullptr;
+#else
+    void* lo = nullptr;
+    float* h = hidden_f32 ? hidden_f32 : (float*)(w + p.h);
+#endif
 
-    // patch embed (conv as GEMM), class token, position table, pre-LayerNorm (which also prepares layer 0's folded LN1)
-    TRY(slime_im2col(pixels, pix_dtype, a_pe, n, d->image, d->patch, d->kpad, dt, stream));
-    TRY(gemm_w(a_pe, d->kpad, d->patch_w, d->patch_w_frag, nullptr, pe_out, D, Mp, D, d->kpad, dt, SLIME_EPI_BIAS_F32, stream));
-    TRY(slime_embed_prenorm(pe_out, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, d->layers_run > 0 ? xn : nullptr,
-                            d->layers_run > 0 ? stats : nullptr, dt, n, P, D, stream));
+    // patch embed (MFMA conv), class token, position table, pre-LayerNorm and the first folded LN1's operand + partial sums: ONE launch
+    TRY(slime_patch_embed_prenorm(pixels, pix_dtype, d->patch_w_frag, d->cls, d->pos, d->pre_ln_w, d->pre_ln_b, d->eps, h, xn, lo, stats,
+                                  dt, n, d->image, d->patch, d->kpad, D, stream));
     // hidden_states[i] of HF's output_hidden_states=True (entry 0 = the pre-LayerNorm'd embeddings, entry i = after layer i):
-    // a device-to-device copy of the fp32 residual stream on the call's stream (capturable), one per state
+    // a device-side copy of the residual stream on the call's stream (capturable), one per state
+#if SLIME_OPT_SPLIT_RESID
+#define SNAPSHOT(idx) TRY(slime_gather_rows_split(xn, lo, dt, S, 0, states + (size_t)(idx) * M * D, SLIME_F32, n, S, D, stream))
+#else
 #define SNAPSHOT(idx)                                                                                                           \
     do {                                                                                                                        \
         if (hipMemcpyAsync(states + (size_t)(idx) * M * D, h, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice,         \
                            (hipStream_t)stream) != hipSuccess) { slime_set_error("vit: hidden-state snapshot failed"); return SLIME_ELAUNCH; } \
     } while (0)
+#endif
     if (states) SNAPSHOT(0);
 
     // Layer loop, 5 launches per layer.  Both LayerNorms are FOLDED into the GEMMs around them (slime_gemm_ex): the GEMM that
@@ -194,52 +210,66 @@ static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, i
     // their partial sums (`stats`); the q/k/v and fc1 GEMMs run on those un-normalised rows with gamma folded into their
     // weights and apply mean / rstd in the epilogue.  No LayerNorm kernel, no fp32 re-read of the residual stream.
     for (int l = 0; l < d->layers_run; ++l) {
-        const char* w_qkv = (const char*)d->w_qkv + (size_t)l * 3 * D * D * 2;
-        const char* w_o = (const char*)d->w_o + (size_t)l * D * D * 2;
-        const char* w_fc1 = (const char*)d->w_fc1 + (size_t)l * F * D * 2;
-        const char* w_fc2 = (const char*)d->w_fc2 + (size_t)l * D * F * 2;
-        const bool last = l + 1 == d->layers_run;
-        auto frag = [&](const void* base, size_t per_layer) -> const void* {     // fragment-order copy of this layer's weight, if packed
+        auto layer_w = [&](const void* base, size_t per_layer) -> const void* {     // this layer's slice of a per-layer weight (or NULL)
             return base ? (const char*)base + (size_t)l * per_layer * 2 : nullptr;
         };
+        const bool last = l + 1 == d->layers_run;
         slime_gemm_args ga{};
         ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
         // q/k/v = LN1(h) Wqkv^T + b  (HF :370-371, :309-311)
-        ga.A = xn; ga.lda = D; ga.B = w_qkv; ga.bias = d->b_qkv + (size_t)l * 3 * D; ga.C = qkv; ga.ldc = 3 * D; ga.N = 3 * D; ga.K = D;
+        ga.A = xn; ga.lda = D; ga.B = layer_w(d->w_qkv, (size_t)3 * D * D); ga.bias = d->b_qkv + (size_t)l * 3 * D; ga.C = qkv; ga.ldc = 3 * D;
+        ga.N = 3 * D; ga.K = D;
         ga.epilogue = SLIME_EPI_BIAS_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_qkv + (size_t)l * 3 * D;
-        ga.B_frag = frag(d->w_qkv_frag, (size_t)3 * D * D);
+        ga.B_frag = layer_w(d->w_qkv_frag, (size_t)3 * D * D);
         PROBED(1, slime_gemm_ex(&ga, stream));
         PROBED(2, slime_attention(qkv, (long)S * 3 * D, 3 * D, qkv + (size_t)D * 2, (long)S * 3 * D, 3 * D,
                                   qkv + (size_t)2 * D * 2, (long)S * 3 * D, 3 * D, ctx, (long)S * D, D, n, d->heads, 64, S, S,
                                   dt, stream));
+        // the two GEMMs that update the residual stream and prepare the next folded LayerNorm
+        auto resid_update = [&](slime_gemm_args& r, bool with_ln) {
+#if SLIME_OPT_SPLIT_RESID
+            (void)with_ln;                                   // the last layer's partial sums are written and never read
+            r.C = xn; r.ldc = D; r.lo16 = lo; r.ldlo = D; r.stats_out = stats; r.epilogue = SLIME_EPI_BIAS_RESID_SPLIT_LN;
+#else
+            r.C = h; r.ldc = D;
+            r.epilogue = with_ln ? SLIME_EPI_BIAS_RESID_F32_LN : SLIME_EPI_BIAS_RESID_F32;
+            if (with_ln) { r.x16 = xn; r.ldx = D; r.stats_out = stats; }
+#endif
+        };
         // h += ctx Wo^T + b; leaves T(h) and its partial sums for LN2  (HF :372-377)
         ga = slime_gemm_args{};
         ga.M = M; ga.dtype = dt;
-        ga.A = ctx; ga.lda = D; ga.B = w_o; ga.bias = d->b_o + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = D;
-        ga.epilogue = SLIME_EPI_BIAS_RESID_F32_LN; ga.x16 = xn; ga.ldx = D; ga.stats_out = stats;
-        ga.B_frag = frag(d->w_o_frag, (size_t)D * D);
+        ga.A = ctx; ga.lda = D; ga.B = layer_w(d->w_o, (size_t)D * D); ga.bias = d->b_o + (size_t)l * D; ga.N = D; ga.K = D;
+        resid_update(ga, true);
+        ga.B_frag = layer_w(d->w_o_frag, (size_t)D * D);
         PROBED(3, slime_gemm_ex(&ga, stream));
         // ff = quick_gelu(LN2(h) W1^T + b)  (HF :379-380, :346-350)
         ga = slime_gemm_args{};
         ga.M = M; ga.dtype = dt; ga.ln_eps = d->eps;
-        ga.A = xn; ga.lda = D; ga.B = w_fc1; ga.bias = d->b_fc1 + (size_t)l * F; ga.C = ff; ga.ldc = F; ga.N = F; ga.K = D;
+        ga.A = xn; ga.lda = D; ga.B = layer_w(d->w_fc1, (size_t)F * D); ga.bias = d->b_fc1 + (size_t)l * F; ga.C = ff; ga.ldc = F; ga.N = F; ga.K = D;
         ga.epilogue = SLIME_EPI_BIAS_QUICKGELU_T; ga.ln_stats = stats; ga.ln_groups = G; ga.ln_colsum = d->colsum_fc1 + (size_t)l * F;
-        ga.B_frag = frag(d->w_fc1_frag, (size_t)F * D);
+        ga.B_frag = layer_w(d->w_fc1_frag, (size_t)F * D);
         PROBED(5, slime_gemm_ex(&ga, stream));
         // h += ff W2^T + b; prepares the next layer's LN1 unless this is the last layer that runs  (HF :381-383)
         ga = slime_gemm_args{};
         ga.M = M; ga.dtype = dt;
-        ga.A = ff; ga.lda = F; ga.B = w_fc2; ga.bias = d->b_fc2 + (size_t)l * D; ga.C = h; ga.ldc = D; ga.N = D; ga.K = F;
-        ga.epilogue = last ? SLIME_EPI_BIAS_RESID_F32 : SLIME_EPI_BIAS_RESID_F32_LN;
-        if (!last) { ga.x16 = xn; ga.ldx = D; ga.stats_out = stats; }
-        ga.B_frag = frag(d->w_fc2_frag, (size_t)D * F);
+        ga.A = ff; ga.lda = F; ga.B = layer_w(d->w_fc2, (size_t)D * F); ga.bias = d->b_fc2 + (size_t)l * D; ga.N = D; ga.K = F;
+        resid_update(ga, !last);
+        ga.B_frag = layer_w(d->w_fc2_frag, (size_t)D * F);
         PROBED(6, slime_gemm_ex(&ga, stream));
         if (states) SNAPSHOT(l + 1);
     }
+#if SLIME_OPT_SPLIT_RESID
+    if (hidden_f32) TRY(slime_gather_rows_split(xn, lo, dt, S, 0, hidden_f32, SLIME_F32, n, S, D, stream));
     if (out) {
         // feature_select: 'patch' drops the class token (clip_encoder.py:38-39), cast to out dtype (:52,56)
+        TRY(slime_gather_rows_split(xn, lo, dt, S, keep_cls ? 0 : 1, out, out_dtype, n, keep_cls ? S : P, D, stream));
+    }
+#else
+    if (out) {
         TRY(slime_gather_rows(h, S, keep_cls ? 0 : 1, out, out_dtype, n, keep_cls ? S : P, D, stream));
     }
+#endif
     return SLIME_OK;
 }
 
@@ -254,8 +284,9 @@ static int resampler_validate(const slime_resampler_desc* d) {
     const int dh = d->dim / d->heads;
     SLIME_REQUIRE(dh == 64 || dh == 128, "resampler: head_dim %d unsupported", dh);
     SLIME_REQUIRE(d->n_query > 0 && d->n_kv > 0, "resampler: empty query/key grid");
-    SLIME_REQUIRE(d->q_proj && d->pos_k && d->ln_kv_w && d->ln_kv_b && d->w_k && d->b_k && d->w_v && d->b_v &&
-                  d->w_o && d->b_o && d->ln_post_w && d->ln_post_b, "resampler: missing weights");
+    // a projection weight is given as its row-major image, its fragment-order image, or both (slime_gemm_b_frag_usable)
+    SLIME_REQUIRE(d->q_proj && d->pos_k && d->ln_kv_w && d->ln_kv_b && (d->w_k || d->w_k_frag) && d->b_k && (d->w_v || d->w_v_frag) && d->b_v &&
+                  (d->w_o || d->w_o_frag) && d->b_o && d->ln_post_w && d->ln_post_b, "resampler: missing weights");
     return SLIME_OK;
 }
 
@@ -309,7 +340,7 @@ static int mlp_validate(const slime_mlp_desc* d) {
     SLIME_REQUIRE(is16(d->dtype), "mlp: dtype must be BF16 or F16");
     SLIME_REQUIRE(d->in_dim == 128 || d->in_dim == 256 || d->in_dim == 1024, "mlp: in_dim=%d unsupported", d->in_dim);
     SLIME_REQUIRE(d->hidden % 128 == 0, "mlp: hidden=%d must be a multiple of 128", d->hidden);
-    SLIME_REQUIRE(d->w1 && d->b1 && d->w2 && d->b2, "mlp: missing weights");
+    SLIME_REQUIRE((d->w1 || d->w1_frag) && d->b1 && (d->w2 || d->w2_frag) && d->b2, "mlp: missing weights (row-major or fragment-order)");
     return SLIME_OK;
 }
 

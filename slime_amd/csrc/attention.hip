@@ -20,6 +20,7 @@
 // at 8-B granularity so that the 8 rows x 4 pieces a half-wave transpose-read touches cover all 64
 // banks.  Softmax statistics are fp32; scores arrive in log2 units (q carries dh^-0.5 * log2 e), exp via v_exp_f32.
 #include "common.h"
+#include <type_traits>
 
 struct AttnArgs {
     const char* q; long q_bs, q_rs;
@@ -602,6 +603,9 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
 // ================================================================================================
 // RING (rows, a power of two; 0 = the resident 608-row panel): K and V live in a ring of RING rows each -- granule gi sits in slot
 // gi mod (RING / 8 NW) -- so a workgroup needs 2 x RING x 128 bytes of LDS instead of 152 KiB (attn64g_kernel below).
+#ifndef SLIME_OPT_ATTN_SHORT_TAIL
+#define SLIME_OPT_ATTN_SHORT_TAIL 1
+#endif
 template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3, int RING = 0>
 __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0,
                                              unsigned long long* t_first = nullptr) {    // diagnostic: when the first granule was ready
@@ -754,11 +758,14 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * RB;
             }
         };
-        auto qk = [&](f32x4 (&sc)[NSUB][2], bool request_next) {
+        // short == true (compile-time at every call site): the LAST step of a ragged key range that fills at most its first 16 rows
+        // (CLIP: 577 = 18 x 32 + 1) -- only the first key tile is multiplied; softmax_pv(short) never looks at sc[.][1]
+        auto qk = [&](f32x4 (&sc)[NSUB][2], bool request_next, auto short_c) {
+            constexpr bool SHORT = decltype(short_c)::value;
             if constexpr (!KPF) k_request();                  // register-lean form: fetch at the point of use
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[1][0]), "+v"(kf[1][1]));
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < (SHORT ? 1 : 2); ++t)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -769,18 +776,22 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                 k_request();
             }
         };
-        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], f32x4 (&nxt)[NSUB][2], bool has_next, bool masked) {
+        auto softmax_pv = [&](int st, f32x4 (&sc)[NSUB][2], f32x4 (&nxt)[NSUB][2], bool has_next, bool masked, auto short_c) {
+            // SHORT (the ragged last step with <= 16 live keys; always masked, never has a next step): one key tile -- 4 V^T reads,
+            // 4 exponentials per query and K = 16 MFMAs (half the matrix time) instead of a 32-key step that is 1/32 useful
+            constexpr bool SHORT = decltype(short_c)::value;
             u32x2 v0[DT], v1[DT];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1] + vring) : lds_tr16_asm<0>(vptr[dt >> 1] + vring);
-                v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1] + vring) : lds_tr16_asm<16 * RB>(vptr[dt >> 1] + vring);
+                if constexpr (!SHORT)
+                    v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1] + vring) : lds_tr16_asm<16 * RB>(vptr[dt >> 1] + vring);
             }
             if constexpr (RING) vring = (vring + 32 * RB) & RMASK;
             else { vptr[0] += 32 * RB; vptr[1] += 32 * RB; }
-            if (masked) {
+            if (masked || SHORT) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < (SHORT ? 1 : 2); ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const bool dead = st * 32 + t * 16 + 4 * g + r >= a.n_kv;
@@ -792,9 +803,13 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
 #pragma unroll
             for (int s = 0; s < NSUB; ++s) {
                 float mx = __builtin_fmaxf(__builtin_fmaxf(sc[s][0][0], sc[s][0][1]), sc[s][0][2]);
-                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
-                mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
-                mx = __builtin_fmaxf(mx, sc[s][1][3]);
+                if constexpr (SHORT) {
+                    mx = __builtin_fmaxf(mx, sc[s][0][3]);
+                } else {
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][0][3]), sc[s][1][0]);
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, sc[s][1][1]), sc[s][1][2]);
+                    mx = __builtin_fmaxf(mx, sc[s][1][3]);
+                }
                 mc[s] = mx;
             }
             // per SUB-BLOCK refresh decision (round 4): see attn64_body -- the result must not depend on which sub-blocks share a wave
@@ -810,7 +825,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                     const float c = -m_run[s];
                     cinit[s] = f32x4{c, c, c, c};
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < (SHORT ? 1 : 2); ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             sc[s][t][r] -= d;
@@ -818,22 +833,37 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
                         }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
-                                                   "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
-            u32x4 vf[DT];
+            if constexpr (SHORT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]));
+                const u32x2 ones2 = {onew, onew};
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vf[dt] = u32x4{v0[dt][0], v0[dt][1], v1[dt][0], v1[dt][1]};
+                for (int s = 0; s < NSUB; ++s) {
+                    // the lane's four scores of key rows 4 g + r are exactly the K = 16 MFMA's B fragment (4 consecutive k per lane);
+                    // v0[dt] = V^T[dh = 16 dt + li][kv = 4 g .. 4 g + 3] is its A fragment
+                    const u32x2 pf = {T::pack2(__builtin_amdgcn_exp2f(sc[s][0][0]), __builtin_amdgcn_exp2f(sc[s][0][1])),
+                                      T::pack2(__builtin_amdgcn_exp2f(sc[s][0][2]), __builtin_amdgcn_exp2f(sc[s][0][3]))};
 #pragma unroll
-            for (int s = 0; s < NSUB; ++s) {
-                float p[8];
+                    for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16_k16(v0[dt], pf, o[s][dt]);
+                    o[s][DT] = T::mfma16_k16(ones2, pf, o[s][DT]);
+                }
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0[0]), "+v"(v0[1]), "+v"(v0[2]), "+v"(v0[3]),
+                                                       "+v"(v1[0]), "+v"(v1[1]), "+v"(v1[2]), "+v"(v1[3]));
+                u32x4 vf[DT];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int dt = 0; dt < DT; ++dt) vf[dt] = u32x4{v0[dt][0], v0[dt][1], v1[dt][0], v1[dt][1]};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(sc[s][t][r]);
-                const u32x4 pf = pack8<T>(p);
+                for (int s = 0; s < NSUB; ++s) {
+                    float p[8];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
-                o[s][DT] = T::mfma16(ones, pf, o[s][DT]);
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[t * 4 + r] = __builtin_amdgcn_exp2f(sc[s][t][r]);
+                    const u32x4 pf = pack8<T>(p);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) o[s][dt] = T::mfma16(vf[dt], pf, o[s][dt]);
+                    o[s][DT] = T::mfma16(ones, pf, o[s][DT]);
+                }
             }
         };
 
@@ -848,24 +878,35 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
 #ifdef SLIME_DIAG
         if (t_first) *t_first = __builtin_amdgcn_s_memtime();
 #endif
+        constexpr std::false_type FULL_STEP{};
+        constexpr std::true_type SHORT_STEP{};
+        // Ragged key range whose last step holds at most 16 live keys (CLIP: 577 = 18 x 32 + 1; round 5, SLIME_OPT_ATTN_SHORT_TAIL):
+        // that step is multiplied half-wide (one key tile, K = 16 MFMAs) instead of as a masked 32-key step.  The choice depends on
+        // n_kv alone, never on the launch form, so the bit-invariance across forms and batch sizes holds.
+        const bool short_tail = SLIME_OPT_ATTN_SHORT_TAIL && !KPF && ragged && (a.n_kv & 31) <= 16 && steps >= 2;
         if constexpr (KPF) k_request();                      // step 0
         if (steps > 1) before_step(1);
-        qk(sA, steps > 1);                                   // multiplies step 0, requests step 1
+        qk(sA, steps > 1, FULL_STEP);                        // multiplies step 0, requests step 1
         int st = 0;
         for (; st + 2 < steps; st += 2) {
             before_step(st + 2);
-            qk(sB, true);                                    // multiplies step st+1, requests step st+2
-            softmax_pv(st, sA, sB, true, false);
+            qk(sB, true, FULL_STEP);                         // multiplies step st+1, requests step st+2
+            softmax_pv(st, sA, sB, true, false, FULL_STEP);
             if (st + 3 < steps) before_step(st + 3);
-            qk(sA, st + 3 < steps);                          // multiplies step st+2, requests step st+3
-            softmax_pv(st + 1, sB, sA, true, false);
+            // multiplies step st+2, requests step st+3; step st+2 may be the short last one (odd step counts: CLIP's 19)
+            if (short_tail && st + 3 == steps) qk(sA, false, SHORT_STEP);
+            else qk(sA, st + 3 < steps, FULL_STEP);
+            softmax_pv(st + 1, sB, sA, true, false, FULL_STEP);
         }
         if (st + 2 == steps) {
-            qk(sB, false);
-            softmax_pv(st, sA, sB, true, false);
-            softmax_pv(st + 1, sB, sA, false, ragged);
+            if (short_tail) qk(sB, false, SHORT_STEP);
+            else qk(sB, false, FULL_STEP);
+            softmax_pv(st, sA, sB, true, false, FULL_STEP);
+            if (short_tail) softmax_pv(st + 1, sB, sA, false, true, SHORT_STEP);
+            else softmax_pv(st + 1, sB, sA, false, ragged, FULL_STEP);
         } else {
-            softmax_pv(st, sA, sB, false, ragged);
+            if (short_tail) softmax_pv(st, sA, sB, false, true, SHORT_STEP);
+            else softmax_pv(st, sA, sB, false, ragged, FULL_STEP);
         }
         if constexpr (!RESIDENT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // granules beyond the last step (short n_kv)
 

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -29,6 +30,10 @@ struct BF16 {
     static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    // half-depth form (K = 16: a lane feeds 4 consecutive k), for ragged tails that fill at most 16 of a 32-deep step
+    static __device__ __forceinline__ f32x4 mfma16_k16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
     }
     // accumulator pinned to the AGPR file (written out: the register allocator otherwise migrates large accumulator
     // sets between the two files around loop back edges)
@@ -64,6 +69,9 @@ struct F16 {
     static __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16_k16(u32x2 a, u32x2 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
     }
     static __device__ __forceinline__ void mfma16_agpr(f32x4& acc, u32x4 a, u32x4 b) {
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));

@@ -86,6 +86,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * one_plus_erf;
 }
 
+// Source of one 16-byte chunk of the static operand inside its FRAGMENT-ORDER image (slime_gemm_pack_b): weight row `nrow` (counted
+// from a 64-aligned row of the image base), 16-byte chunk `kc` (0..7) of a 64-wide k-tile.  Unit index ((t KS + s) 4 + f) 64 + lane
+// with t = nrow / 64, s = 2 ktile + (kc >> 2), lane = (kc & 3) 16 + c and nrow % 64 = 32 (f >> 1) + 8 (c >> 2) + 4 (f & 1) + (c & 3):
+// a permutation of the row-major image's 16-byte chunks, so the LDS-staged kernels can DMA exactly the bytes they always staged
+// from the fragment image alone (round 5: no second, row-major copy of a packed weight; results bit-identical).  The k-tile
+// advance is FRAG_KTILE_BYTES instead of 128.
+constexpr unsigned FRAG_KTILE_BYTES = 2 * 4 * 64 * 16;
+__device__ __forceinline__ unsigned frag_chunk_offset(const int nrow, const int kc, const int K) {
+    const int t = nrow >> 6, r = nrow & 63;
+    const int f = ((r >> 5) << 1) | ((r >> 2) & 1), c = (((r >> 3) & 3) << 2) | (r & 3);
+    return ((((unsigned)t * (unsigned)(K >> 5) + (unsigned)(kc >> 2)) * 4u + (unsigned)f) * 64u + (unsigned)((kc & 3) * 16 + c)) * 16u;
+}
+
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T || EPI == SLIME_EPI_BIAS_RESID_T); };
 
 // Wave-level epilogue.  A lane owns, for every 16-row step i and column-tile pair p, 8 consecutive
@@ -239,6 +252,65 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                             *reinterpret_cast<float2*>(g.stats_out + ((size_t)row * (g.N >> 6) + ((col_base + 64 * pp) >> 6)) * 2) = make_float2(sx, sq);
                     }
                 }
+            }
+        }
+    } else if constexpr (EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN) {
+        // The residual update on a 2 x 16-bit SPLIT stream (round 5): h = float(hi) + float(lo) (exact in fp32: the two halves do not
+        // overlap), c = acc + (bias + h), hi' = T(c), lo' = T(c - float(hi')) (the difference is exact), partial sums of c as in
+        // BIAS_RESID_F32_LN.  hi' IS the next GEMM's operand: 8 bytes per element cross the fabric here (2 + 2 in, 2 + 2 out)
+        // instead of 10 (4 in, 4 + 2 out); what is kept of c are 16 (bf16) / 22 (fp16) significant bits instead of 24.
+        // C (= hi) and lo are read and written in place and vmcnt counts stores: both planes are fetched one 16-row step ahead
+        // (one step, not two as the fp32 epilogue: two planes' addresses + unpacked halves must fit the direct-B kernel's 128 VGPRs).
+        u32x4 rb[2][NP][2];
+        char* Hi = reinterpret_cast<char*>(g.C);
+        char* Lo = g.lo;
+        auto load_step = [&](int i, int buf) {
+            int row = row_base + i * 16;
+            if constexpr (!FULL) row = min(row, g.M - 1);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                rb[buf][p][0] = ld_stream(reinterpret_cast<const u32x4*>(Hi + ((size_t)row * g.ldc + col_base + 32 * p) * 2));
+                rb[buf][p][1] = ld_stream(reinterpret_cast<const u32x4*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p) * 2));
+            }
+        };
+        load_step(0, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if (i + 1 < MI) load_step(i + 1, (i + 1) & 1);
+            const int row = row_base + i * 16;
+#pragma unroll
+            for (int pp = 0; pp < NP / 2; ++pp) {
+                float sx = 0.f, sq = 0.f;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int p = 2 * pp + h2;
+                    const u32x4 rh = rb[i & 1][p][0], rl = rb[i & 1][p][1];
+                    u32x4 w, wl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {                    // word e = columns 2e, 2e+1 of the lane's 8: accumulator block 2p + (e >> 1)
+                        const float c0 = acc[i][2 * p + (e >> 1)][(2 * e) & 3] + (bias[p][2 * e] + (T::lo(rh[e]) + T::lo(rl[e])));
+                        const float c1 = acc[i][2 * p + (e >> 1)][(2 * e + 1) & 3] + (bias[p][2 * e + 1] + (T::hi(rh[e]) + T::hi(rl[e])));
+                        acc[i][2 * p + (e >> 1)][(2 * e) & 3] = c0;
+                        acc[i][2 * p + (e >> 1)][(2 * e + 1) & 3] = c1;
+                        w[e] = T::pack2(c0, c1);
+                        wl[e] = T::pack2(c0 - T::lo(w[e]), c1 - T::hi(w[e]));
+                    }
+                    if (in_range(row)) {
+                        st_stream(reinterpret_cast<u32x4*>(Hi + ((size_t)row * g.ldc + col_base + 32 * p) * 2), w);
+                        st_stream(reinterpret_cast<u32x4*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p) * 2), wl);
+                    }
+                    // partial sums in the element order of BIAS_RESID_F32_LN
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float a0 = acc[i][2 * p][k], a1 = acc[i][2 * p + 1][k];
+                        sx += a0; sx += a1;
+                        sq = fmaf(a0, a0, sq); sq = fmaf(a1, a1, sq);
+                    }
+                }
+                sx = rows4_allsum(sx);
+                sq = rows4_allsum(sq);
+                if ((col_base & 31) == 0 && in_range(row))
+                    *reinterpret_cast<float2*>(g.stats_out + ((size_t)row * (g.N >> 6) + ((col_base + 64 * pp) >> 6)) * 2) = make_float2(sx, sq);
             }
         }
     } else if constexpr (EPI == SLIME_EPI_BIAS_RESID_T) {
@@ -433,12 +505,17 @@ gemm_kernel(GemmArgs g) {
         const int gm = min(m0 + r, g.M - 1);          // clamp: rows past M re-read the last row
         a_src[i] = g.A + ((size_t)gm * g.lda) * 2 + lchunk * 16;
     }
+    // the static operand comes from its row-major image (k-tile advance 128 bytes) or, when the caller passed B = NULL, from the
+    // fragment-order image alone (frag_chunk_offset: the same 16-byte chunks at permuted addresses, k-tile advance 8 KiB)
+    const bool bfrag = g.B == nullptr;
+    const int b_kstep = bfrag ? (int)FRAG_KTILE_BYTES : BK * 2;
+    const char* b_tile0 = (bfrag ? g.Bimg : g.B) + (size_t)n0 * g.K * 2;     // BN % 64 == 0: n0 rows = n0 / 64 whole fragment tiles
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         const int rho = (i * NW + wave) * 8 + lrow;   // LDS row
         const int nl = rho & 15;
         const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-        b_src[i] = g.B + ((size_t)(n0 + nphys) * g.K) * 2 + lchunk * 16;
+        b_src[i] = b_tile0 + (bfrag ? (size_t)frag_chunk_offset(nphys, lchunk, g.K) : ((size_t)nphys * g.K) * 2 + lchunk * 16);
     }
 
     auto stage = [&](int s) {
@@ -453,7 +530,7 @@ gemm_kernel(GemmArgs g) {
         for (int i = 0; i < B_INSTR; ++i) {
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(b_src[i]),
                                              LDS_PTR(base + A_BYTES + (i * NW + wave) * 1024), 16, 0, 0);
-            b_src[i] += BK * 2;
+            b_src[i] += b_kstep;
         }
     };
 
@@ -494,15 +571,15 @@ gemm_kernel(GemmArgs g) {
         for (int i = 0; i < B_INSTR; ++i) {
             const int rho = (i * NW + wave) * 8 + lrow, nl = rho & 15;
             const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-            soff[A_INSTR + i] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+            soff[A_INSTR + i] = bfrag ? frag_chunk_offset(nphys, lchunk, g.K) : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
         }
         const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
-        const char* b_gbase = g.B + (size_t)n0 * g.K * 2;
+        const char* b_gbase = b_tile0;
         const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_byte_addr(smem));
         auto stage3 = [&](int tile) {
             const unsigned base = lds0 + (tile % 3) * STAGE;
             const char* ga = uniform_ptr(a_gbase + (size_t)tile * (BK * 2));
-            const char* gb = uniform_ptr(b_gbase + (size_t)tile * (BK * 2));
+            const char* gb = uniform_ptr(b_gbase + (size_t)tile * b_kstep);
 #pragma unroll
             for (int i = 0; i < A_INSTR; ++i) lds_dma16(soff[i], ga, base + (i * NW + wave) * 1024);
 #pragma unroll
@@ -710,7 +787,10 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     // global_load_lds: half the address VGPR traffic per piece and no 64-bit VALU pointer arithmetic in the L sections;
     // the k advance is a scalar add on the base.
     const char* a_base = g.A + (size_t)m0 * g.lda * 2;
-    const char* b_base = g.B + (size_t)n0 * g.K * 2;
+    // static operand: row-major image, or (B = NULL) the fragment-order image alone (frag_chunk_offset; k-tile advance 8 KiB, not 128 B)
+    const bool bfrag = g.B == nullptr;
+    const char* b_base = (bfrag ? g.Bimg : g.B) + (size_t)n0 * g.K * 2;
+    const size_t b_kstep = bfrag ? FRAG_KTILE_BYTES : BK * 2;
     unsigned soff[4][2];
     int dst[4][2];                                       // byte offset inside a stage
 #pragma unroll
@@ -731,13 +811,13 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             const int rho = chunk * 64 + hb * 32 + sub * 8 + lrow;
             const int nl = rho & 15;
             const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-            soff[1 + hb][j] = (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+            soff[1 + hb][j] = bfrag ? frag_chunk_offset(nphys, lchunk, g.K) : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
             dst[1 + hb][j] = A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
         }
     }
     auto issue = [&](int kind, int tile) {               // 2 pieces of `kind` for k-tile `tile`
         char* base = smem + (tile & 1) * STAGE;
-        const char* gb = uniform_ptr((kind == 0 || kind == 3 ? a_base : b_base) + (size_t)tile * (BK * 2));
+        const char* gb = uniform_ptr(kind == 0 || kind == 3 ? a_base + (size_t)tile * (BK * 2) : b_base + (size_t)tile * b_kstep);
         const unsigned lb = __builtin_amdgcn_readfirstlane(lds_byte_addr(base));
 #pragma unroll
         for (int j = 0; j < 2; ++j) lds_dma16(soff[kind][j], gb, lb + dst[kind][j]);
@@ -1940,10 +2020,11 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
+    if (!g.B && (tile == 5 || tile == 6 || tile == 7 || tile == 8)) tile = 4;        // persistent / 32x32 ping-pong variants stage row-major B only
     if ((tile == 1 || (tile >= 4 && tile != 15)) && g.N % 256 != 0) tile = 3;
     if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
-    if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T)) tile = 4;     // the 32x32 variant has neither epilogue
+    if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T || EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
@@ -1958,6 +2039,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
         tile = g.Bf ? 12 : 11;
     }
 #endif
+    // B = NULL (the caller holds the fragment-order image only): the lock-step, ping-pong and direct-B kernels read it; the stream
+    // kernel (never picked by auto_tile when a fragment image exists) is replaced by the direct-B kernel, or the ping-pong one
+    if (!g.B && (tile == 10 || tile == 11)) tile = g.Bf ? 12 : 4;
     if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
@@ -1982,6 +2066,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
         case SLIME_EPI_BIAS_RESID_F32_LN: return launch_epi<T, SLIME_EPI_BIAS_RESID_F32_LN>(g, stream);
         case SLIME_EPI_BIAS_RESID_T: return launch_epi<T, SLIME_EPI_BIAS_RESID_T>(g, stream);
         case SLIME_EPI_BIAS_GELU_MIX_T: return launch_db<T, SLIME_EPI_BIAS_GELU_MIX_T, 8>(g, stream);    // direct-B only (checked by slime_gemm_ex)
+        case SLIME_EPI_BIAS_RESID_SPLIT_LN: return launch_epi<T, SLIME_EPI_BIAS_RESID_SPLIT_LN>(g, stream);
     }
     slime_set_error("gemm: unknown epilogue %d", epi);
     return SLIME_EINVAL;
@@ -1992,7 +2077,7 @@ static int launch_T(const GemmArgs& g, int epi, hipStream_t stream) {
 extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilogue, int b_frag, char* out, size_t out_len) {
     SLIME_REQUIRE(out && out_len > 0 && M > 0 && N > 0 && K > 0, "gemm_kernel_name: bad input");
     GemmArgs g{nullptr, nullptr, nullptr, nullptr, K, N, M, N, K, 0, nullptr, nullptr, 0, nullptr, 0.f, nullptr, 0, nullptr,
-               b_frag ? "" : nullptr, 0, nullptr, 0};
+               (b_frag && N % 256 == 0) ? "" : nullptr, 0, nullptr, 0};       // a fragment image makes the direct-B kernel eligible at N % 256 == 0 only
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
@@ -2006,11 +2091,13 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
 extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     SLIME_REQUIRE(a, "gemm: null argument block");
     const int M = a->M, N = a->N, K = a->K, lda = a->lda, ldc = a->ldc;
-    SLIME_REQUIRE(a->A && a->B && a->C, "gemm: null pointer");
+    SLIME_REQUIRE(a->A && a->C && (a->B || a->B_frag), "gemm: null pointer");
     SLIME_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: empty shape M=%d N=%d K=%d", M, N, K);
     SLIME_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
     SLIME_REQUIRE(N % 128 == 0, "gemm: N=%d must be a multiple of 128", N);
     SLIME_REQUIRE(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 8 == 0, "gemm: bad leading dims lda=%d ldc=%d", lda, ldc);
+    SLIME_REQUIRE(a->B || (slime_gemm_b_frag_usable(N, K) && ((uintptr_t)a->B_frag % 16) == 0),
+                  "gemm: B = NULL needs a fragment-order image this shape can run from (slime_gemm_b_frag_usable)");
     SLIME_REQUIRE(((uintptr_t)a->A % 16 == 0) && ((uintptr_t)a->B % 16 == 0) && ((uintptr_t)a->C % 16 == 0) &&
                   (!a->bias || (uintptr_t)a->bias % 16 == 0), "gemm: pointers must be 16-byte aligned");
     if (a->ln_stats) {
@@ -2023,6 +2110,10 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     if (a->epilogue == SLIME_EPI_BIAS_RESID_F32_LN)
         SLIME_REQUIRE(a->x16 && a->stats_out && a->ldx >= N && a->ldx % 8 == 0 && ((uintptr_t)a->x16 % 16) == 0 &&
                       ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0, "gemm: BIAS_RESID_F32_LN needs x16 [M, ldx] and stats_out [M, N/64, 2]");
+    if (a->epilogue == SLIME_EPI_BIAS_RESID_SPLIT_LN)
+        SLIME_REQUIRE(a->lo16 && a->stats_out && a->ldlo >= N && a->ldlo % 8 == 0 && ((uintptr_t)a->lo16 % 16) == 0 &&
+                      ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0 && a->lo16 != a->C,
+                      "gemm: BIAS_RESID_SPLIT_LN needs the split residual stream C = hi T [M, ldc], lo16 T [M, ldlo] and stats_out [M, N/64, 2]");
     if (a->epilogue == SLIME_EPI_BIAS_RESID_T)
         SLIME_REQUIRE(a->resid && a->ldr >= N && a->ldr % 8 == 0 && ((uintptr_t)a->resid % 16) == 0,
                       "gemm: BIAS_RESID_T needs resid T [M, ldr >= N] (16-byte aligned, ldr a multiple of 8)");
@@ -2033,13 +2124,16 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
                       "gemm: BIAS_GELU_MIX_T runs on the direct-B kernel only: needs B_frag (N %% 256 == 0), A2 [M, lda] and mix_gates [M, 2]");
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
                a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
-               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr, (const char*)a->A2, a->mix_gates};
+               frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr, (const char*)a->A2, a->mix_gates,
+               (char*)a->lo16, a->ldlo, (const char*)a->B_frag};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);
     slime_set_error("gemm: dtype %d is not a 16-bit MFMA type", a->dtype);
     return SLIME_EINVAL;
 }
+
+extern "C" int slime_gemm_b_frag_usable(int N, int K) { return (N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0) ? 1 : 0; }
 
 extern "C" size_t slime_gemm_packed_b_bytes(int N, int K) { return (N > 0 && K > 0) ? (size_t)N * K * 2 : 0; }
 
@@ -2056,8 +2150,9 @@ extern "C" int slime_gemm_pack_b(const void* B, int N, int K, void* out, void* s
 
 extern "C" int slime_gemm(const void* A, int lda, const void* B, const float* bias, void* C, int ldc,
                           int M, int N, int K, int dtype, int epilogue, void* stream) {
-    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN && epilogue != SLIME_EPI_BIAS_RESID_T && epilogue != SLIME_EPI_BIAS_GELU_MIX_T,
-                  "gemm: BIAS_RESID_F32_LN / BIAS_RESID_T / BIAS_GELU_MIX_T take extra operands: use slime_gemm_ex");
+    SLIME_REQUIRE(epilogue != SLIME_EPI_BIAS_RESID_F32_LN && epilogue != SLIME_EPI_BIAS_RESID_T && epilogue != SLIME_EPI_BIAS_GELU_MIX_T &&
+                  epilogue != SLIME_EPI_BIAS_RESID_SPLIT_LN,
+                  "gemm: BIAS_RESID_F32_LN / BIAS_RESID_T / BIAS_GELU_MIX_T / BIAS_RESID_SPLIT_LN take extra operands: use slime_gemm_ex");
     slime_gemm_args a{};
     a.A = A; a.lda = lda; a.B = B; a.bias = bias; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.dtype = dtype; a.epilogue = epilogue;
     return slime_gemm_ex(&a, stream);

@@ -421,7 +421,7 @@ static int llama_validate(const slime_llama_attn_desc* d) {
     SLIME_REQUIRE(d->dtype == SLIME_BF16 || d->dtype == SLIME_F16, "llama_attn: dtype must be BF16 or F16");
     SLIME_REQUIRE(d->head_dim == 128 && d->n_heads > 0 && d->n_kv_heads > 0 && d->n_heads % d->n_kv_heads == 0, "llama_attn: heads");
     SLIME_REQUIRE(d->hidden % 128 == 0 && d->hidden % 64 == 0, "llama_attn: hidden=%d must be a multiple of 128", d->hidden);
-    SLIME_REQUIRE(d->w_qkv && d->w_o && d->inv_freq, "llama_attn: missing weights");
+    SLIME_REQUIRE((d->w_qkv || d->w_qkv_frag) && (d->w_o || d->w_o_frag) && d->inv_freq, "llama_attn: missing weights (row-major or fragment-order)");
     return SLIME_OK;
 }
 

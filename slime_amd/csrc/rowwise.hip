@@ -1,5 +1,6 @@
-// rowwise.hip -- HBM-bound row kernels: LayerNorm (+cast/+position term), im2col for the patch
-// embed, cls/pos/pre-LN embedding assembly, gate mix, row gather / spatial merge, tile+normalise.
+// rowwise.hip -- HBM-bound row kernels: LayerNorm (+cast/+position term), gate mix, row gather / spatial merge,
+// tile+normalise.  (The patch-embed front end -- im2col, class token, position table, pre-LayerNorm -- is ONE MFMA kernel
+// since round 5: patch_embed.hip.)
 // One wave (64 lanes) owns one row; loads are 16 B/lane (float4) wherever the width allows.
 #include "common.h"
 
@@ -108,182 +109,6 @@ extern "C" int slime_layernorm(const float* x, int ldx, int rows, int D, const f
     LnArgs a{x, ldx, rows, w, b, eps, normalize, out_f32, out_t, out_t2, add, add_period};
     if (dtype == SLIME_F16) return launch_ln<F16>(a, D, (hipStream_t)stream);
     return launch_ln<BF16>(a, D, (hipStream_t)stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// im2col for the patch-embed conv.  One workgroup = one row of patches of one crop: the 3 x patch image rows
-// it needs (3 x 14 rows of 336 pixels = 28 KB in T) are fetched with 16-byte coalesced loads into LDS (fp32
-// pixels are rounded to T on the way), then the [g patches, kpad] operand rows are written 16 B per lane, each
-// element looked up through a k -> (c, ky, kx) table built once per workgroup.  Column k = (c, ky, kx); columns
-// >= 3*patch^2 are the zero padding of the GEMM's K dimension.
-// ------------------------------------------------------------------------------------------------
-template <typename T, typename PixT>
-__global__ void __launch_bounds__(256) im2col_kernel(const PixT* px, unsigned short* out, int image, int patch, int kpad) {
-    extern __shared__ __attribute__((aligned(16))) char smem_i2c[];
-    unsigned short* tile = reinterpret_cast<unsigned short*>(smem_i2c);              // [3*patch][image]
-    const int g = image / patch, pp = patch * patch, kreal = 3 * pp, nrows = 3 * patch;
-    unsigned short* lut = tile + (size_t)nrows * image;                               // [kpad]: LDS offset of column k, 0xffff = pad
-    const int crop = blockIdx.x / g, pyi = blockIdx.x % g, tid = threadIdx.x;
-
-    for (int k = tid; k < kpad; k += 256) {
-        unsigned short v = 0xffffu;
-        if (k < kreal) { const int c = k / pp, r = k % pp; v = (unsigned short)((c * patch + r / patch) * image + r % patch); }
-        lut[k] = v;
-    }
-    constexpr int EPC = 16 / (int)sizeof(PixT);                                       // pixels per 16-byte chunk
-    const int cpr = image / EPC;                                                      // chunks per image row
-    for (int i = tid; i < nrows * cpr; i += 256) {
-        const int r = i / cpr, q = i % cpr, c = r / patch, ky = r % patch;
-        const PixT* src = px + (((size_t)crop * 3 + c) * image + (size_t)pyi * patch + ky) * image + (size_t)q * EPC;
-        unsigned short* dst = tile + (size_t)r * image + q * EPC;
-        if constexpr (sizeof(PixT) == 4) {
-            const float4 f = *reinterpret_cast<const float4*>(src);
-            u32x2 w = {T::pack2(f.x, f.y), T::pack2(f.z, f.w)};
-            *reinterpret_cast<u32x2*>(dst) = w;
-        } else {
-            *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);    // pixels already in T (checked on the host)
-        }
-    }
-    __syncthreads();
-    const int chunks = kpad / 8;
-    unsigned short* orow = out + ((size_t)crop * g * g + (size_t)pyi * g) * kpad;
-    for (int i = tid; i < g * chunks; i += 256) {
-        const int pxi = i / chunks, ch = i % chunks;
-        unsigned w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned short o0 = lut[ch * 8 + 2 * j], o1 = lut[ch * 8 + 2 * j + 1];
-            const unsigned lo = o0 == 0xffffu ? 0u : tile[o0 + pxi * patch];
-            const unsigned hi = o1 == 0xffffu ? 0u : tile[o1 + pxi * patch];
-            w[j] = lo | (hi << 16);
-        }
-        *reinterpret_cast<u32x4*>(orow + (size_t)pxi * kpad + ch * 8) = u32x4{w[0], w[1], w[2], w[3]};
-    }
-}
-
-extern "C" int slime_im2col(const void* pixels, int pix_dtype, void* out, int n, int image, int patch,
-                            int kpad, int dtype, void* stream) {
-    SLIME_REQUIRE(pixels && out && n > 0, "im2col: bad input");
-    SLIME_REQUIRE(image % patch == 0 && kpad % 8 == 0 && kpad >= 3 * patch * patch, "im2col: bad geometry");
-    SLIME_REQUIRE(pix_dtype == SLIME_F32 || pix_dtype == dtype, "im2col: 16-bit pixels must already be in the tower dtype");
-    SLIME_REQUIRE(image % 8 == 0 && ((uintptr_t)pixels % 16) == 0, "im2col: image width must be a multiple of 8 and pixels 16-byte aligned");
-    SLIME_REQUIRE((size_t)3 * patch * image < 65535, "im2col: tile too large for the 16-bit offset table");
-    const int g = image / patch;
-    const size_t lds = ((size_t)3 * patch * image + kpad) * 2;
-    SLIME_REQUIRE(lds <= 64 * 1024, "im2col: %zu bytes of LDS needed", lds);
-    hipStream_t s = (hipStream_t)stream;
-    unsigned short* o = (unsigned short*)out;
-    const dim3 grid(n * g), block(256);
-    if (dtype == SLIME_F16) {
-        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<F16, float>), grid, block, lds, s, (const float*)pixels, o, image, patch, kpad);
-        else hipLaunchKernelGGL((im2col_kernel<F16, unsigned short>), grid, block, lds, s, (const unsigned short*)pixels, o, image, patch, kpad);
-    } else {
-        if (pix_dtype == SLIME_F32) hipLaunchKernelGGL((im2col_kernel<BF16, float>), grid, block, lds, s, (const float*)pixels, o, image, patch, kpad);
-        else hipLaunchKernelGGL((im2col_kernel<BF16, unsigned short>), grid, block, lds, s, (const unsigned short*)pixels, o, image, patch, kpad);
-    }
-    SLIME_CHECK_LAUNCH("im2col");
-    return SLIME_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// h[n, 1+P, D] = pre_layrnorm(cat(cls, patch_out) + pos)
-// ------------------------------------------------------------------------------------------------
-template <typename T, int VPL>
-__global__ void __launch_bounds__(256) embed_prenorm_kernel(const float* patch_out, const float* cls, const float* pos,
-                                                            const float* w, const float* b, float eps, float* h,
-                                                            char* x16, float* stats, int n, int P) {
-    constexpr int D = 64 * VPL;
-    constexpr int VEC = (VPL >= 4) ? 4 : 2;
-    constexpr int NV = VPL / VEC;
-    constexpr int LPG = 64 / VEC;                       // lanes that share one 64-column group of a chunk
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long)n * (P + 1)) return;
-    const int t = (int)(row % (P + 1));
-    const long crop = row / (P + 1);
-    const float* src = t == 0 ? cls : patch_out + (crop * P + (t - 1)) * D;
-    const float* pr = pos + (size_t)t * D;
-    float v[VPL];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[i * VEC + j] = src[c + j] + pr[c + j];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) s += v[i];
-    const float mean = wave_sum(s) * (1.0f / D);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
-    float* o = h + row * D;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            v[i * VEC + j] = (v[i * VEC + j] - mean) * rstd * w[c + j] + b[c + j];
-            o[c + j] = v[i * VEC + j];
-        }
-    }
-    if (x16) {
-        // first LayerNorm of the layer stack folded into the q/k/v GEMM (slime_gemm_ex): the rows rounded to T and the
-        // (sum, sum of squares) of the rounded values per 64-column group.  Chunk i holds columns 64 VEC i ..: its LPG-lane
-        // groups are the 64-column groups.
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (i * 64 + lane) * VEC;
-            float sx = 0.f, sq = 0.f;
-            if constexpr (VEC == 4) {
-                u32x2 pk = {T::pack2(v[i * 4], v[i * 4 + 1]), T::pack2(v[i * 4 + 2], v[i * 4 + 3])};
-                *reinterpret_cast<u32x2*>(x16 + ((size_t)row * D + c) * 2) = pk;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) { const float lo = T::lo(pk[k]), hi = T::hi(pk[k]); sx += lo; sx += hi; sq = fmaf(lo, lo, sq); sq = fmaf(hi, hi, sq); }
-            } else {
-                const unsigned pk = T::pack2(v[i * 2], v[i * 2 + 1]);
-                *reinterpret_cast<unsigned*>(x16 + ((size_t)row * D + c) * 2) = pk;
-                const float lo = T::lo(pk), hi = T::hi(pk);
-                sx = lo + hi; sq = fmaf(lo, lo, hi * hi);
-            }
-#pragma unroll
-            for (int off = LPG / 2; off > 0; off >>= 1) { sx += __shfl_xor(sx, off); sq += __shfl_xor(sq, off); }
-            if ((lane & (LPG - 1)) == 0)
-                *reinterpret_cast<float2*>(stats + ((size_t)row * (D / 64) + (c >> 6)) * 2) = make_float2(sx, sq);
-        }
-    }
-}
-
-extern "C" int slime_embed_prenorm(const float* patch_out, const float* cls, const float* pos, const float* ln_w,
-                                   const float* ln_b, float eps, float* h, void* x16, float* stats, int dtype, int n, int P,
-                                   int D, void* stream) {
-    SLIME_REQUIRE(patch_out && cls && pos && ln_w && ln_b && h && n > 0 && P > 0, "embed_prenorm: bad input");
-    SLIME_REQUIRE((x16 == nullptr) == (stats == nullptr), "embed_prenorm: x16 and stats come together");
-    SLIME_REQUIRE(!x16 || dtype == SLIME_BF16 || dtype == SLIME_F16, "embed_prenorm: x16 dtype must be BF16 or F16");
-    const long rows = (long)n * (P + 1);
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    char* x = (char*)x16;
-#define EP_LAUNCH(TT, V) hipLaunchKernelGGL((embed_prenorm_kernel<TT, V>), grid, block, 0, s, patch_out, cls, pos, ln_w, ln_b, eps, h, x, stats, n, P)
-    if (dtype == SLIME_F16) {
-        switch (D) {
-            case 128: EP_LAUNCH(F16, 2); break;
-            case 256: EP_LAUNCH(F16, 4); break;
-            case 1024: EP_LAUNCH(F16, 16); break;
-            default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
-        }
-    } else {
-        switch (D) {
-            case 128: EP_LAUNCH(BF16, 2); break;
-            case 256: EP_LAUNCH(BF16, 4); break;
-            case 1024: EP_LAUNCH(BF16, 16); break;
-            default: slime_set_error("embed_prenorm: D=%d unsupported", D); return SLIME_EINVAL;
-        }
-    }
-#undef EP_LAUNCH
-    SLIME_CHECK_LAUNCH("embed_prenorm");
-    return SLIME_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -467,6 +292,51 @@ extern "C" int slime_gather_rows(const float* in, int rows_in, int row_off, void
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        in, rows_in, row_off, out, out_dtype, total, rows_out, C);
     SLIME_CHECK_LAUNCH("gather_rows");
+    return SLIME_OK;
+}
+
+// The same from a 2 x 16-bit split residual stream (tower, round 5): in = float(hi) + float(lo), 8 elements per lane per step.
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_split_kernel(const char* hi, const char* lo, int rows_in, int row_off, void* out,
+                                                                int out_dtype, long total, int rows_out, int C) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= total) return;
+    const long g = r / rows_out, i = r % rows_out;
+    const size_t src = ((size_t)g * rows_in + row_off + i) * C * 2;
+    for (int c = lane * 8; c < C; c += 512) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(hi + src + (size_t)c * 2), b = *reinterpret_cast<const u32x4*>(lo + src + (size_t)c * 2);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[2 * e] = T::lo(a[e]) + T::lo(b[e]); v[2 * e + 1] = T::hi(a[e]) + T::hi(b[e]); }
+        if (out_dtype == SLIME_F32) {
+            float* d = reinterpret_cast<float*>(out) + (size_t)r * C + c;
+            *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if (out_dtype == SLIME_F16) {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ((size_t)r * C + c) * 2) = pack8<F16>(v);
+        } else {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + ((size_t)r * C + c) * 2) = pack8<BF16>(v);
+        }
+    }
+}
+
+extern "C" int slime_gather_rows_split(const void* hi, const void* lo, int dtype, int rows_in, int row_off, void* out, int out_dtype,
+                                       int groups, int rows_out, int C, void* stream) {
+    SLIME_REQUIRE(hi && lo && out && groups > 0 && rows_out > 0 && C % 8 == 0, "gather_rows_split: bad input");
+    SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "gather_rows_split: the stream halves are BF16 or F16");
+    SLIME_REQUIRE(out_dtype == SLIME_F32 || out_dtype == SLIME_BF16 || out_dtype == SLIME_F16, "gather_rows_split: bad out dtype");
+    SLIME_REQUIRE(row_off >= 0 && row_off + rows_out <= rows_in, "gather_rows_split: window outside the group");
+    SLIME_REQUIRE(((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo % 16) == 0 && ((uintptr_t)out % 16) == 0, "gather_rows_split: 16-byte alignment");
+    const long total = (long)groups * rows_out;
+    const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+    if (dtype == SLIME_F16)
+        hipLaunchKernelGGL(gather_rows_split_kernel<F16>, grid, block, 0, (hipStream_t)stream, (const char*)hi, (const char*)lo, rows_in, row_off,
+                           out, out_dtype, total, rows_out, C);
+    else
+        hipLaunchKernelGGL(gather_rows_split_kernel<BF16>, grid, block, 0, (hipStream_t)stream, (const char*)hi, (const char*)lo, rows_in, row_off,
+                           out, out_dtype, total, rows_out, C);
+    SLIME_CHECK_LAUNCH("gather_rows_split");
     return SLIME_OK;
 }
 

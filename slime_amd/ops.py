@@ -9,6 +9,7 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import math
+import os
 import threading
 import weakref
 from dataclasses import dataclass, field
@@ -66,13 +67,13 @@ class Workspace:
 
 def pack_b_frag(w: torch.Tensor) -> Optional[torch.Tensor]:
     """Copy of the static GEMM operand(s) w T [..., N, K] in MFMA-fragment order (slime_gemm_pack_b; layout in
-    include/slime_hip.h), or None where the direct-B kernel cannot use it (N % 256, K % 64, host tensors)."""
+    include/slime_hip.h), or None where the library cannot run from it (it is asked: slime_gemm_b_frag_usable; host tensors)."""
     if w is None or not w.is_cuda:
         return None
     N, K = w.shape[-2], w.shape[-1]
-    if N % 256 != 0 or K % 64 != 0:
-        return None
     lib = _lib.load()
+    if not lib.slime_gemm_b_frag_usable(N, K):
+        return None
     w = w.contiguous()
     out = torch.empty_like(w)
     per = N * K * w.element_size()
@@ -82,13 +83,41 @@ def pack_b_frag(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
-def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
+def keep_row_major() -> bool:
+    """Weight-memory policy.  Since ABI 5 every kernel slime_gemm_ex dispatches to can read a static operand from
+    its fragment-order image alone, so by default a packed weight is resident ONCE (tower 0.58 GB, adapter 62 MB; through round 4
+    every weight was held twice: row-major for the LDS-staged kernels + fragment order for the direct-B kernel).
+    SLIME_KEEP_ROW_MAJOR=1 keeps the row-major copies as well (the round-4 layout; results are bit-identical either way)."""
+    return os.environ.get("SLIME_KEEP_ROW_MAJOR", "0") == "1"
+
+
+def pack_static(T: Dict[str, Optional[torch.Tensor]], names: Sequence[str]) -> None:
+    """T[name + '_frag'] = fragment-order image of T[name]; the row-major tensor is dropped (T[name] = None) where the library can
+    run from the image alone, unless keep_row_major()."""
+    for name in names:
+        T[name + "_frag"] = pack_b_frag(T[name])
+        if T[name + "_frag"] is not None and not keep_row_major():
+            T[name] = None
+
+
+def packed_weight_bytes(*packs) -> int:
+    """Resident bytes of the packed tensors of PackedTower / PackedResampler / PackedMlp / ... objects (each tensor once)."""
+    seen, total = set(), 0
+    for p in packs:
+        for t in (p.tensors if hasattr(p, "tensors") else p).values():
+            if isinstance(t, torch.Tensor) and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+    return total
+
+
+def gemm(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], epilogue: int,
          out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]; w_frag = pack_b_frag(w) (optional); resid T [M,N] for
     EPI_BIAS_RESID_T (out = T(a @ w.T + bias + resid), out may be resid)."""
     lib = _lib.load()
     M, K = a.shape
-    N = w.shape[0]
+    N = (w if w is not None else w_frag).shape[0]        # w = None: the fragment-order image alone (slime_gemm_b_frag_usable)
     if out is None:
         odt = a.dtype if (epilogue <= _lib.EPI_BIAS_GELU_T or epilogue == _lib.EPI_BIAS_RESID_T) else torch.float32
         out = torch.empty((M, N), dtype=odt, device=a.device)
@@ -104,7 +133,7 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     """h (fp32, in place) += a @ w.T + bias; returns (x16 = T(h), stats [M, N/64, 2]): SLIME_EPI_BIAS_RESID_F32_LN."""
     lib = _lib.load()
     M, K = a.shape
-    N = w.shape[0]
+    N = (w if w is not None else w_frag).shape[0]
     x16 = torch.empty((M, N), dtype=a.dtype, device=a.device)
     stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
     g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(h), ldc=h.stride(0), M=M, N=N, K=K,
@@ -114,13 +143,47 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return x16, stats
 
 
+def gemm_resid_split(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], hi: torch.Tensor, lo: torch.Tensor,
+                     w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """SLIME_EPI_BIAS_RESID_SPLIT_LN on the 2 x 16-bit split residual stream (hi, lo: T [M, N], updated in place):
+    c = a @ w.T + bias + (float(hi) + float(lo)); hi = T(c); lo = T(c - float(hi)).  Returns stats [M, N/64, 2] (partial sums of c)."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = (w if w is not None else w_frag).shape[0]
+    stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
+    g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(hi), ldc=hi.stride(0), M=M, N=N, K=K,
+                      dtype=dtype_code(a.dtype), epilogue=_lib.EPI_BIAS_RESID_SPLIT_LN, stats_out=_ptr(stats), B_frag=_ptr(w_frag),
+                      lo16=_ptr(lo), ldlo=lo.stride(0))
+    _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
+    return stats
+
+
+def patch_embed_prenorm(pixels: torch.Tensor, patch_w_frag: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, ln_w: torch.Tensor,
+                        ln_b: torch.Tensor, eps: float, dtype: torch.dtype, image: int, patch: int, kpad: int, want_h=True, want_x16=True,
+                        want_lo=False):
+    """slime_patch_embed_prenorm: pixels [n,3,image,image] (fp32 or T) -> (h fp32 [n*(1+P), D] | None, x16 T | None, lo T | None,
+    stats [n*(1+P), D/64, 2] | None)."""
+    lib = _lib.load()
+    n, D = pixels.shape[0], cls.shape[0]
+    rows = n * ((image // patch) ** 2 + 1)
+    dev = pixels.device
+    h = torch.empty((rows, D), dtype=torch.float32, device=dev) if want_h else None
+    x16 = torch.empty((rows, D), dtype=dtype, device=dev) if want_x16 else None
+    lo = torch.empty((rows, D), dtype=dtype, device=dev) if want_lo else None
+    stats = torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev) if want_x16 else None
+    _lib.check(lib.slime_patch_embed_prenorm(_ptr(pixels), dtype_code(pixels.dtype), _ptr(patch_w_frag), _ptr(cls), _ptr(pos), _ptr(ln_w),
+                                             _ptr(ln_b), float(eps), _ptr(h), _ptr(x16), _ptr(lo), _ptr(stats), dtype_code(dtype), n, image,
+                                             patch, kpad, D, _stream()), "slime_patch_embed_prenorm")
+    return h, x16, lo, stats
+
+
 def gemm_ln_consumer(x16: torch.Tensor, stats: torch.Tensor, w_folded: torch.Tensor, bias_folded: torch.Tensor, colsum: torch.Tensor,
                      eps: float, epilogue: int, w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """epi(LayerNorm(x16) @ W.T + b) with the LayerNorm folded: w_folded = T(W diag(gamma)), bias_folded = b + W beta,
     colsum = row sums of w_folded; stats from the producer.  Output T [M, N]."""
     lib = _lib.load()
     M, K = x16.shape
-    N = w_folded.shape[0]
+    N = (w_folded if w_folded is not None else w_frag).shape[0]
     out = torch.empty((M, N), dtype=x16.dtype, device=x16.device)
     g = _lib.GemmArgs(A=_ptr(x16), lda=x16.stride(0), B=_ptr(w_folded), bias=_ptr(bias_folded), C=_ptr(out), ldc=N, M=M, N=N, K=K,
                       dtype=dtype_code(x16.dtype), epilogue=epilogue, ln_stats=_ptr(stats), ln_groups=stats.shape[1],
@@ -249,10 +312,15 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
         T["w_fc1"], T["b_fc1"], T["colsum_fc1"] = dev_stack(w1), dev_stack(b1), dev_stack(c1)
         T["w_o"], T["b_o"] = stack(p + "self_attn.out_proj.weight", tt), stack(p + "self_attn.out_proj.bias", f32)
         T["w_fc2"], T["b_fc2"] = stack(p + "mlp.fc2.weight", tt), stack(p + "mlp.fc2.bias", f32)
-        # fragment-order copies for the direct-B GEMM kernel (None at geometries it does not serve: the descriptor field stays NULL)
-        for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
-            T[name + "_frag"] = pack_b_frag(T[name])
-    T["patch_w_frag"] = pack_b_frag(T["patch_w"])
+        # fragment-order images (the direct-B kernel loads them straight into registers, the LDS-staged kernels DMA from them);
+        # the row-major tensors are dropped unless SLIME_KEEP_ROW_MAJOR=1
+        pack_static(T, ("w_qkv", "w_o", "w_fc1", "w_fc2"))
+    T["patch_w_frag"] = pack_b_frag(T["patch_w"])          # the front end (slime_patch_embed_prenorm) reads this image only
+    if T["patch_w_frag"] is None:
+        if not T["patch_w"].is_cuda:
+            raise _lib.SlimeHipError("pack_tower: weights are packed on the GPU (slime_gemm_pack_b): slime_amd has no CPU path")
+        raise ValueError("pack_tower: the patch-embed weight could not be packed (hidden size and padded patch size must be multiples of 64)")
+    T["patch_w"] = None
     d = _lib.VitDesc()
     d.hidden, d.inter, d.heads, d.layers_run = D, Fi, cfg.num_attention_heads, L
     d.image, d.patch, d.kpad, d.dtype, d.eps = cfg.image_size, cfg.patch_size, kpad, dtype_code(dtype), cfg.layer_norm_eps
@@ -329,11 +397,12 @@ def tower_kernel_names(pt: PackedTower, n_crops: int) -> Dict[int, str]:
     M, D, Fi = n_crops * cfg.seq_len, cfg.hidden_size, cfg.intermediate_size
     t = "F16" if pt.dtype == torch.float16 else "BF16"
     fr = {k: pt.tensors.get(k + "_frag") is not None for k in ("w_qkv", "w_o", "w_fc1", "w_fc2")}
+    resid_epi = _lib.load().slime_vit_residual_epilogue()      # what this build's tower launches for out_proj / fc2
     return {1: gemm_kernel_name(M, 3 * D, D, pt.dtype, _lib.EPI_BIAS_T, fr["w_qkv"]),
             2: f"attn64r_kernel<{t}, 3>" if 321 <= cfg.seq_len <= 608 and cfg.head_dim == 64 else f"attn_kernel<{t}, 64, 608, 8, 5>",
             5: gemm_kernel_name(M, Fi, D, pt.dtype, _lib.EPI_BIAS_QUICKGELU_T, fr["w_fc1"]),
-            3: gemm_kernel_name(M, D, D, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_o"]),
-            6: gemm_kernel_name(M, D, Fi, pt.dtype, _lib.EPI_BIAS_RESID_F32_LN, fr["w_fc2"])}
+            3: gemm_kernel_name(M, D, D, pt.dtype, resid_epi, fr["w_o"]),
+            6: gemm_kernel_name(M, D, Fi, pt.dtype, resid_epi, fr["w_fc2"])}
 
 
 @dataclass
@@ -387,8 +456,7 @@ def pack_resampler(sd: Dict[str, torch.Tensor], dim: int, heads: int, n_kv: int,
          "w_k": tt(in_w[E:2 * E]), "b_k": f32(in_b[E:2 * E]), "w_v": tt(in_w[2 * E:]), "b_v": f32(in_b[2 * E:]),
          "w_o": tt(sd["attn.out_proj.weight"]), "b_o": f32(sd["attn.out_proj.bias"]),
          "ln_post_w": f32(sd["ln_post.weight"]), "ln_post_b": f32(sd["ln_post.bias"])}
-    for k in ("w_k", "w_v", "w_o"):
-        T[k + "_frag"] = pack_b_frag(T[k])
+    pack_static(T, ("w_k", "w_v", "w_o"))
     d = _lib.ResamplerDesc()
     d.dim, d.heads, d.n_query, d.n_kv, d.dtype, d.eps = dim, heads, nq, n_kv, dtype_code(dtype), eps
     for k, v in T.items():
@@ -428,7 +496,7 @@ def pack_mlp(w1, b1, w2, b2, dtype: torch.dtype, device) -> PackedMlp:
          "b1": b1.detach().to(device=device, dtype=torch.float32).contiguous(),
          "w2": w2.detach().to(device=device, dtype=torch.float32).to(dtype).contiguous(),
          "b2": b2.detach().to(device=device, dtype=torch.float32).contiguous()}
-    T["w1_frag"], T["w2_frag"] = pack_b_frag(T["w1"]), pack_b_frag(T["w2"])
+    pack_static(T, ("w1", "w2"))
     d = _lib.MlpDesc()
     d.in_dim, d.hidden, d.dtype = w1.shape[1], w1.shape[0], dtype_code(dtype)
     for k, v in T.items():
@@ -821,7 +889,7 @@ def pack_llama_attention(wq, wk, wv, wo, n_heads: int, n_kv_heads: int, dtype: t
 
     T = {"w_qkv": tt(torch.cat([wq.detach().float().cpu(), wk.detach().float().cpu(), wv.detach().float().cpu()], 0)),
          "w_o": tt(wo), "inv_freq": llama_inv_freq(dh, rope_theta).to(device)}
-    T["w_qkv_frag"], T["w_o_frag"] = pack_b_frag(T["w_qkv"]), pack_b_frag(T["w_o"])
+    pack_static(T, ("w_qkv", "w_o"))
     d = _lib.LlamaAttnDesc()
     d.hidden, d.n_heads, d.n_kv_heads, d.head_dim, d.dtype = D, n_heads, n_kv_heads, dh, dtype_code(dtype)
     for k, v in T.items():

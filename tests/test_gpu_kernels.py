@@ -112,7 +112,11 @@ def test_gemm_pack_b_layout(dev, dtype, N, K):
     stacked = torch.stack([w, w.flip(0)])                  # per-layer stacks are packed slice by slice
     wf2 = ops.pack_b_frag(stacked)
     assert torch.equal(wf2[0], wf) and torch.equal(wf2[1], _frag_order_reference(w.flip(0).contiguous()))
-    assert ops.pack_b_frag(_rand((384, 128), dtype, dev, 12)) is None       # N % 256: the kernel does not serve it
+    # ABI 5: every [N % 64, K % 64] operand can be run from its fragment image (the library is asked, not a rule restated here)
+    lib = ops._lib.load()
+    assert lib.slime_gemm_b_frag_usable(384, 128) == 1 and ops.pack_b_frag(_rand((384, 128), dtype, dev, 12)) is not None
+    assert lib.slime_gemm_b_frag_usable(96, 128) == 0 and ops.pack_b_frag(_rand((96, 128), dtype, dev, 12)) is None
+    assert lib.slime_gemm_b_frag_usable(128, 96) == 0
 
 
 def _check_direct_b(dev, dtype, M, N, K, forced):
@@ -427,46 +431,161 @@ def test_layernorm(dev, D, dtype):
     assert torch.equal(ot.cpu(), x.to(dtype).cpu())
 
 
-def test_im2col_and_embed(dev):
+def _patch_embed_reference(sd, cfg, px, dt):
+    """The oracle's embeddings (oracle.clip_embeddings = HF CLIPVisionEmbeddings) + pre_layrnorm on the SAME rounded operands the
+    kernel multiplies: pixels and conv weight rounded to T, everything else fp32."""
+    import oracle.slime_oracle as O
+    from slime_amd import weights as W
+    tsd = {k: v.clone() for k, v in W.strip_tower_prefix(sd).items()}
+    tsd["embeddings.patch_embedding.weight"] = tsd["embeddings.patch_embedding.weight"].to(dt).float()
+    x = O.clip_embeddings(tsd, px.float().cpu().to(dt).float(), cfg.patch_size)
+    return F.layer_norm(x, (cfg.hidden_size,), tsd["pre_layrnorm.weight"], tsd["pre_layrnorm.bias"], cfg.layer_norm_eps)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", ["vit_l_20_crops", "tiny_3_crops"])
+def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
+    """slime_patch_embed_prenorm (round 5: im2col + conv GEMM + class token + position table + pre-LayerNorm in ONE launch) against
+    the oracle's CLIPVisionEmbeddings + pre_layrnorm -- at the bench step's launch shape (20 crops of ViT-L/14-336: 240 workgroups of
+    48 rows x 1024 columns) and at the tiny test geometry (hidden 128: two waves per workgroup), fp32 and T pixels, with every output:
+    fp32 rows, T(h), the split stream's lower half, partial sums of the ROUNDED rows."""
+    from slime_amd import ops, weights as W, _lib
+    cfg = W.CLIP_L_336 if geom.startswith("vit_l") else W.TINY
+    n = 20 if geom.startswith("vit_l") else 3
+    sd = W.make_tower_state_dict(cfg, seed=77)
+    pt = ops.pack_tower(sd, cfg, dt, dev, select_layer=0)              # layers_run = 0: embeddings only
+    T = pt.tensors
+    px = W.synthetic_pixels(n, seed=5).to(dev)
+    D, P, S = cfg.hidden_size, cfg.num_patches, cfg.seq_len
+    kpad = pt.desc.kpad
+    ref = _patch_embed_reference(sd, cfg, px, dt).reshape(n * S, D)
+    h, x16, lo, stats = ops.patch_embed_prenorm(px, T["patch_w_frag"], T["cls"], T["pos"], T["pre_ln_w"], T["pre_ln_b"], cfg.layer_norm_eps,
+                                                dt, cfg.image_size, cfg.patch_size, kpad, want_lo=True)
+    assert rel_l2(h.cpu(), ref) < TOL_F32
+    per_row = ((h.cpu() - ref).norm(dim=1) / ref.norm(dim=1)).max()
+    assert float(per_row) < 5 * TOL_F32, float(per_row)               # no stray row (class-token rows, workgroup seams, last patch row)
+    assert torch.equal(x16, h.to(dt))                                  # the GEMM operand is T(h) exactly
+    d = h - x16.float()
+    assert torch.equal(lo, d.to(dt))                                   # the split stream's lower half is T(h - T(h)) exactly
+    bits = 16 if dt == torch.bfloat16 else 21
+    assert float(((x16.float() + lo.float()) - h).abs().max() / h.abs().max()) < 2.0 ** -bits
+    xr = x16.float().view(n * S, D // 64, 64)
+    assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
+    # pixels already in T: the same bits (fp32 pixels are rounded to T on the way in, clip_encoder.py:55)
+    h2, x2, _, st2 = ops.patch_embed_prenorm(px.to(dt), T["patch_w_frag"], T["cls"], T["pos"], T["pre_ln_w"], T["pre_ln_b"],
+                                             cfg.layer_norm_eps, dt, cfg.image_size, cfg.patch_size, kpad)
+    assert torch.equal(h2, h) and torch.equal(x2, x16) and torch.equal(st2, stats)
+    # batch invariance: a crop's rows do not depend on its position in the batch or on the batch size
+    h3, _, _, _ = ops.patch_embed_prenorm(px[n - 1:], T["patch_w_frag"], T["cls"], T["pos"], T["pre_ln_w"], T["pre_ln_b"], cfg.layer_norm_eps,
+                                          dt, cfg.image_size, cfg.patch_size, kpad)
+    assert torch.equal(h3, h[(n - 1) * S:])
+    # the tower driver's entry 0 (hidden_states[0]) is this kernel's output
+    st = ops.tower_hidden_states(pt, px)
+    assert st.shape[0] == 1 and rel_l2(st[0].reshape(n * S, D).cpu(), ref) < (2.0 ** -15 if dt == torch.bfloat16 else 2e-5) + TOL_F32
+    lib = _lib.load()
+    with pytest.raises(_lib.SlimeHipError, match="lo16"):              # the lower half comes with its upper half
+        _lib.check(lib.slime_patch_embed_prenorm(px.data_ptr(), _lib.F32, T["patch_w_frag"].data_ptr(), T["cls"].data_ptr(), T["pos"].data_ptr(),
+                                                 T["pre_ln_w"].data_ptr(), T["pre_ln_b"].data_ptr(), 1e-5, h.data_ptr(), None, lo.data_ptr(), None,
+                                                 ops.dtype_code(dt), n, cfg.image_size, cfg.patch_size, kpad, D, 0))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,tile", [(11540, 1024, 4096, 0), (11540, 1024, 1024, 0), (2885, 1024, 4096, 0), (577, 1024, 1024, 0),
+                                        (1731, 1024, 1024, 4), (300, 768, 640, 3), (2308, 512, 128, 15), (1731, 1024, 1024, 12),
+                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 1)])
+def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
+    """SLIME_EPI_BIAS_RESID_SPLIT_LN (round 5): the residual update on a 2 x 16-bit split stream.  Against fp32 torch on the same
+    operands: hi' = T(c) EXACTLY for c = the kernel's own fp32 result (checked through the fp32 epilogue, which computes the same c
+    when fed h = float(hi) + float(lo)), lo' = T(c - hi') exactly, hi' + lo' within 2^-16 (bf16) / 2^-21 (fp16) of c, partial sums
+    of c; and bit-equal across kernel families (auto dispatch with / without the fragment image, forced tiles)."""
+    from slime_amd import ops, _lib
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    h0 = _rand((M, N), torch.float32, dev, 4, 2.0) + 0.3
+    h0[:, 5] *= 50.0                                                   # an outlier channel
+    hi0 = h0.to(dtype)
+    lo0 = (h0 - hi0.float()).to(dtype)
+    hsum = hi0.float() + lo0.float()                                   # what the stream holds
+
+    def run(with_frag, with_w=True):
+        hi, lo = hi0.clone(), lo0.clone()
+        st = ops.gemm_resid_split(a, w if with_w else None, bias, hi, lo, w_frag=wf if with_frag else None)
+        return hi, lo, st
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(tile)
+        try:
+            hi, lo, st = run(True)
+            c = hsum.clone()
+            ops.gemm(a, w, bias, _lib.EPI_BIAS_RESID_F32, out=c, w_frag=wf)          # the same fp32 c, through the fp32 epilogue
+        finally:
+            lib.slime_gemm_force_tile(0)
+    ref = hsum.double() + a.double() @ w.double().t() + bias.double()
+    assert rel_l2(c, ref) < TOL_F32
+    assert torch.equal(hi, c.to(dtype)), "upper half must be T(c)"
+    assert torch.equal(lo, (c - hi.float()).to(dtype)), "lower half must be T(c - T(c))"
+    bits = 16 if dtype == torch.bfloat16 else 21
+    err = ((hi.float() + lo.float()) - c).abs() / c.abs().clamp_min(1e-3)
+    assert float(err.max()) < 2.0 ** -bits, float(err.max())
+    cr = c.view(M, N // 64, 64)
+    assert rel_l2(st[..., 0], cr.sum(-1)) < 1e-5 and rel_l2(st[..., 1], (cr * cr).sum(-1)) < 1e-5
+    if tile == 0:
+        # product dispatch: with the fragment image (direct-B / ping-pong), without it (LDS-staged), and from the image ALONE
+        for args in ((False, True), (True, False)):
+            hi2, lo2, st2 = run(*args)
+            assert torch.equal(hi2, hi) and torch.equal(lo2, lo) and torch.equal(st2, st), args
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,tile", [(11540, 1024, 4096, 0), (11540, 4096, 1024, 0), (2885, 1024, 4096, 0), (577, 3072, 1024, 0), (577, 1024, 4096, 0),
+                                        (4608, 1024, 1024, 0), (300, 768, 640, 0), (77, 256, 64, 0), (2308, 512, 128, 0), (1731, 1024, 1024, 4),
+                                        (1731, 1024, 1024, 9), (1731, 1024, 1024, 3), (1731, 1024, 1024, 15), (1731, 1024, 1024, 1),
+                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 5), (1731, 1024, 1024, 7)])
+def test_gemm_from_fragment_image_alone(dev, dtype, M, N, K, tile):
+    """ABI 5: with B = NULL every kernel the dispatch can reach takes the static operand from the fragment-order
+    image -- the LDS-staged kernels DMA the same 16-byte chunks from permuted addresses -- and the result is BIT-IDENTICAL to the
+    row-major path: auto dispatch at the tower's shapes (fc2's ping-pong kernel, the small-grid 128 x 128 kernels, N % 256 != 0) and
+    forced tiles (4 / 9 ping-pong, 3 / 15 / 1 lock-step; 11 / 5 / 7 cannot read the image and are re-routed)."""
+    from slime_amd import ops, _lib
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    assert wf is not None
+    h0 = _rand((M, N), torch.float32, dev, 4, 2.0)
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(tile)
+        try:
+            for epi in (_lib.EPI_BIAS_F32, _lib.EPI_BIAS_T, _lib.EPI_BIAS_QUICKGELU_T):
+                want = ops.gemm(a, w, bias, epi)
+                assert torch.equal(ops.gemm(a, None, bias, epi, w_frag=wf), want), epi
+            h1, h2 = h0.clone(), h0.clone()
+            x1, s1 = ops.gemm_ln_producer(a, w, bias, h1)
+            x2, s2 = ops.gemm_ln_producer(a, None, bias, h2, w_frag=wf)
+            assert torch.equal(h1, h2) and torch.equal(x1, x2) and torch.equal(s1, s2)
+        finally:
+            lib.slime_gemm_force_tile(0)
+    with pytest.raises(_lib.SlimeHipError, match="null pointer"):
+        ops.gemm(a, None, bias, _lib.EPI_BIAS_F32, out=torch.empty((M, N), dtype=torch.float32, device=dev))
+
+
+def test_gather_rows_split(dev):
+    """slime_gather_rows_split: the tower's final feature_select / cast from the 2 x 16-bit split residual stream."""
     from slime_amd import _lib
     lib = _lib.load()
-    n, image, patch, D = 2, 336, 14, 128
-    g = image // patch
-    px = _rand((n, 3, image, image), torch.float32, dev, 11)
-    kpad = 640
-    out = torch.empty((n * g * g, kpad), dtype=torch.bfloat16, device=dev)
     st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.slime_im2col(px.data_ptr(), _lib.F32, out.data_ptr(), n, image, patch, kpad, _lib.BF16, st))
-    ref = F.unfold(px, kernel_size=patch, stride=patch).transpose(1, 2).reshape(n * g * g, 588)   # (c,ky,kx) order
-    assert torch.equal(out[:, :588].cpu(), ref.to(torch.bfloat16).cpu())
-    assert float(out[:, 588:].float().abs().max()) == 0
-    # 16-bit pixels path
-    pxh = px.to(torch.bfloat16)
-    out2 = torch.empty_like(out)
-    _lib.check(lib.slime_im2col(pxh.data_ptr(), _lib.BF16, out2.data_ptr(), n, image, patch, kpad, _lib.BF16, st))
-    assert torch.equal(out2.cpu(), out.cpu())
-    # embed + pre-LN
-    P = g * g
-    pe = _rand((n * P, D), torch.float32, dev, 12)
-    cls = _rand((D,), torch.float32, dev, 13)
-    pos = _rand((P + 1, D), torch.float32, dev, 14)
-    w = _rand((D,), torch.float32, dev, 15) * 0.1 + 1
-    b = _rand((D,), torch.float32, dev, 16) * 0.1
-    h = torch.empty((n, P + 1, D), dtype=torch.float32, device=dev)
-    _lib.check(lib.slime_embed_prenorm(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5,
-                                       h.data_ptr(), None, None, _lib.BF16, n, P, D, st))
-    x = torch.cat([cls.expand(n, 1, D), pe.view(n, P, D)], 1) + pos
-    assert rel_l2(h.cpu(), F.layer_norm(x, (D,), w, b, 1e-5).cpu()) < TOL_F32
-    # ... and with the outputs that prepare the first folded LayerNorm: x16 = T(h) exactly, partial sums of the ROUNDED rows
+    n, S, D = 3, 577, 1024
     for dt, code in ((torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
-        h2 = torch.empty_like(h)
-        x16 = torch.empty((n * (P + 1), D), dtype=dt, device=dev)
-        stats = torch.empty((n * (P + 1), D // 64, 2), dtype=torch.float32, device=dev)
-        _lib.check(lib.slime_embed_prenorm(pe.data_ptr(), cls.data_ptr(), pos.data_ptr(), w.data_ptr(), b.data_ptr(), 1e-5,
-                                           h2.data_ptr(), x16.data_ptr(), stats.data_ptr(), code, n, P, D, st))
-        assert torch.equal(h2, h) and torch.equal(x16, h.view(-1, D).to(dt))
-        xr = x16.float().view(-1, D // 64, 64)
-        assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
+        h = _rand((n * S, D), torch.float32, dev, 21, 3.0)
+        hi = h.to(dt)
+        lo = (h - hi.float()).to(dt)
+        want = (hi.float() + lo.float()).view(n, S, D)
+        for odt, ocode in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
+            for off, rows in ((1, S - 1), (0, S)):
+                out = torch.empty((n, rows, D), dtype=odt, device=dev)
+                _lib.check(lib.slime_gather_rows_split(hi.data_ptr(), lo.data_ptr(), code, S, off, out.data_ptr(), ocode, n, rows, D, st))
+                assert torch.equal(out, want[:, off:off + rows].to(odt))
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])

@@ -28,7 +28,7 @@ def test_library_exports_exactly_the_header():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(lib, s), f"libslime_hip.so does not export {s}"
-    assert lib.slime_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.slime_abi_version() == _lib.ABI_VERSION == 5
     assert _exported(_lib.LIB_PATH) == syms
     assert set(_lib._SIGNATURES) == syms, "slime_amd/_lib.py binds exactly the header's functions"
     if os.path.exists(_lib.DIAG_LIB_PATH):
@@ -498,6 +498,6 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     assert (int(got["SLIME_BF16"]), int(got["SLIME_F16"]), int(got["SLIME_F32"]), int(got["SLIME_U8"])) == (_lib.BF16, _lib.F16, _lib.F32, _lib.U8)
     assert int(got["SLIME_ABI_VERSION"]) == _lib.ABI_VERSION
     epi = [e for e in enums if e.startswith("SLIME_EPI_")]
-    assert len(epi) == 8
+    assert len(epi) == 9
     for e in epi:
         assert int(got[e]) == getattr(_lib, e[len("SLIME_"):]), e

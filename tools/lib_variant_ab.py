@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of product-library variants (tools/build_variants.sh) on the 40-crop tower: each variant runs in its own process (one library
 per process), rounds interleaved; prints ms per 40 crops (two streams x 20 | one stream x 40) and a checksum of the features so that
-bit-equality across variants is visible.  usage: lib_variant_ab.py [--rounds R] name ...   (name 'product' = slime_amd/libslime_hip.so)"""
+bit-equality across variants is visible.  usage: lib_variant_ab.py [--rounds R] name[@KEY=VAL[,KEY=VAL]] ...   (name 'product' =
+slime_amd/libslime_hip.so; the optional @ part sets environment variables for that variant's process, e.g. product@SLIME_KEEP_ROW_MAJOR=1)"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -9,7 +10,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import time, hashlib, torch
     sys.path.insert(0, ROOT)
     from slime_amd import _lib
-    name = sys.argv[2]
+    label = sys.argv[2]
+    name = label.split("@")[0]
     if name != "product":
         _lib.LIB_PATH = os.path.join(ROOT, "slime_amd", "variants", f"libslime_hip_{name}.so")
     from slime_amd import ops, weights as W
@@ -38,7 +40,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             for _ in range(12): fn()
             torch.cuda.synchronize(); best.append((time.perf_counter() - t0) / 12 * 1e3)
         ts.append(sorted(best)[1])
-    rec = {"name": name, "two": ts[0], "one": ts[1], "sha": h}
+    rec = {"name": label, "two": ts[0], "one": ts[1], "sha": h, "weight_MB": round(ops.packed_weight_bytes(pts[0]) / 1e6, 1)}
     if os.environ.get("AB_ADAPTER") == "1":
         # the bench step's second half: fused adapter over the 40 crops' features (8 images x (1+4)), alone and behind the two-stream tower
         asd = W.make_adapter_state_dict(W.ADAPTER_8B, seed=4321)
@@ -48,7 +50,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         ad = lambda: ops.adapter_forward(pg, post, feats, 8, 4, 2, 2, True, -1, dt)
         out = ad(); torch.cuda.synchronize()
         rec["adapter_sha"] = hashlib.sha1(out.float().cpu().numpy().tobytes()).hexdigest()[:12]
-        torch.save(out.float().cpu(), f"/tmp/ab_adapter_{name}.pt")
+        torch.save(out.float().cpu(), f"/tmp/ab_adapter_{label}.pt")
 
         def step():
             x, y = run2(); return ops.adapter_forward(pg, post, torch.cat([x, y]), 8, 4, 2, 2, True, -1, dt)
@@ -77,11 +79,14 @@ def _rel():
 
 for r in range(rounds):
     for n in args:
-        o = subprocess.run([sys.executable, __file__, "--child", n], capture_output=True, text=True, timeout=600)
+        env = dict(os.environ)
+        if "@" in n:
+            env.update(kv.split("=", 1) for kv in n.split("@", 1)[1].split(","))
+        o = subprocess.run([sys.executable, __file__, "--child", n], capture_output=True, text=True, timeout=600, env=env)
         try:
             d = json.loads(o.stdout.strip().splitlines()[-1])
             extra = f" | adapter {d['adapter']:.3f} ms, tower + adapter {d['step']:.2f} ms, adapter sha {d['adapter_sha']}" if "adapter" in d else ""
-            print(f"{d['name']:24s}: {d['two']:6.2f} | {d['one']:6.2f} | {d['sha']}{extra}", flush=True)
+            print(f"{d['name']:36s}: {d['two']:6.2f} | {d['one']:6.2f} | {d['sha']} | weights {d.get('weight_MB')} MB{extra}", flush=True)
         except Exception:
             print(n, "FAILED", o.stderr[-600:], flush=True)
 _rel()
