@@ -97,12 +97,14 @@ PROBE_KERNELS = {1: ("qkv_proj", 3072, 1024), 3: ("out_proj+residual", 1024, 102
                  6: ("fc2+residual", 1024, 4096), 2: ("attention", 0, 0), 0: ("layernorm1", -1, 0), 4: ("layernorm2", -1, 0)}
 
 
-def gemm_algorithmic_bytes(kid, M, N, K):
+def gemm_algorithmic_bytes(kid, M, N, K, split_residual=True):
     """Bytes one launch of a tower GEMM has to move if every operand crossed the fabric exactly once."""
     b = M * K * 2 + N * K * 2 + N * 4                       # A, W (16 bit), bias
     if kid in (1, 5):                                       # q/k/v, fc1: LayerNorm-fold consumer, T output
         return b + M * N * 2 + M * (K // 64) * 8 + N * 4    # + output, row partial sums, colsum
-    return b + 2 * M * N * 4 + M * N * 2 + M * (N // 64) * 8   # out_proj / fc2: fp32 residual read + write, T(h), partial sums
+    if split_residual:                                      # out_proj / fc2 on the 2 x 16-bit split residual stream (round 5): hi + lo read and written
+        return b + 4 * M * N * 2 + M * (N // 64) * 8
+    return b + 2 * M * N * 4 + M * N * 2 + M * (N // 64) * 8   # rounds 1-4: fp32 residual read + write, T(h), partial sums
 
 
 def kernel_roofline(vision_model, pixels_half, reps=1):
@@ -142,7 +144,8 @@ def kernel_roofline(vision_model, pixels_half, reps=1):
         per[kid] = {"label": label, "rocprof_name": names[kid], "ms": round(avg, 4), "min_ms": round(min(ms), 4), "max_ms": round(max(ms), 4),
                     "launches_timed": len(ms), "tflops": round(fl / avg / 1e9, 1), "gflop_per_launch": round(fl / 1e9, 2), "M": M, "N": N, "K": K}
         if N > 0:
-            per[kid]["algorithmic_bytes"] = gemm_algorithmic_bytes(kid, M, N, K)
+            split = ops._lib.load().slime_vit_residual_epilogue() == ops._lib.EPI_BIAS_RESID_SPLIT_LN
+            per[kid]["algorithmic_bytes"] = gemm_algorithmic_bytes(kid, M, N, K, split)
         if N < 0:
             per[kid]["gb_per_s"] = round(M * 1024 * 6 / avg / 1e6, 1)          # fp32 in + 16-bit out
     dom = max((k for k in per if per[k]["N"] > 0), key=lambda k: per[k]["ms"])
@@ -472,6 +475,10 @@ def main():
                        "crops_per_gpu": per_rank, "images_per_step": IMAGES * (1 if strong else world), "grid": f"1+{LOCAL}",
                        "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),
                        "tower_streams": halves,
+                       # resident packed weights (each tensor once): since ABI 5 a weight lives in HBM as its fragment-order image only
+                       "packed_weight_MB": {"tower": round(ops.packed_weight_bytes(tower.vision_tower.packed(-2, 0)) / 1e6, 1),
+                                            "adapter": round(ops.packed_weight_bytes(pg.mlp, pg.attn, post) / 1e6, 1),
+                                            "row_major_copies_kept": ops.keep_row_major()},
                        "step_pipelining": "none" if tail_stream is None else "gather+adapter of step i on a second stream, under the tower of step i+1",
                        **extra_cfg},
             "path_mfma": {"algorithmic_tflops": round(path_tflops, 1), "frac_of_peak": round(path_tflops / (PEAK_BF16_TFLOPS * world), 4),

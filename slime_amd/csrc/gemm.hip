@@ -86,17 +86,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * one_plus_erf;
 }
 
-// Source of one 16-byte chunk of the static operand inside its FRAGMENT-ORDER image (slime_gemm_pack_b): weight row `nrow` (counted
-// from a 64-aligned row of the image base), 16-byte chunk `kc` (0..7) of a 64-wide k-tile.  Unit index ((t KS + s) 4 + f) 64 + lane
-// with t = nrow / 64, s = 2 ktile + (kc >> 2), lane = (kc & 3) 16 + c and nrow % 64 = 32 (f >> 1) + 8 (c >> 2) + 4 (f & 1) + (c & 3):
-// a permutation of the row-major image's 16-byte chunks, so the LDS-staged kernels can DMA exactly the bytes they always staged
-// from the fragment image alone (round 5: no second, row-major copy of a packed weight; results bit-identical).  The k-tile
-// advance is FRAG_KTILE_BYTES instead of 128.
-constexpr unsigned FRAG_KTILE_BYTES = 2 * 4 * 64 * 16;
-__device__ __forceinline__ unsigned frag_chunk_offset(const int nrow, const int kc, const int K) {
-    const int t = nrow >> 6, r = nrow & 63;
-    const int f = ((r >> 5) << 1) | ((r >> 2) & 1), c = (((r >> 3) & 3) << 2) | (r & 3);
-    return ((((unsigned)t * (unsigned)(K >> 5) + (unsigned)(kc >> 2)) * 4u + (unsigned)f) * 64u + (unsigned)((kc & 3) * 16 + c)) * 16u;
+// The static operand staged from its FRAGMENT-ORDER image alone (round 5: B = NULL, no row-major copy of a packed weight).  One
+// fragment (64-column tile t, k-step s, fragment f) is 1 KiB contiguous in the image: 64 lanes x 16 B, lane = 16 lq + c for the 16
+// weight rows c of MFMA block 4 t + f and the four 8-wide k groups lq of the k-step.  An LDS-DMA piece writes 64 lanes x 16 B
+// lane-linearly, so the fragment is copied AS IT IS (one fully coalesced 1 KiB read, no swizzle): the LDS image of a B tile in this
+// mode is [16-row block][k-step][lane] -- a block is 2 KiB exactly as in the row-major image ([16 rows][128 B]), so the main loops'
+// block offsets stay, and the fragment read of lane l for k-step ks is simply block + ks * 1024 + 16 l (64 consecutive 16-byte
+// reads: conflict free).  Same bytes into the same MFMAs: results are bit-identical to the row-major path.
+// frag_piece_offset: byte offset of (block blk counted from the tile's first row, k-step ks of the k-tile) inside the image,
+// relative to the tile's first fragment; the k-tile advance is FRAG_KTILE_BYTES instead of 128.
+constexpr unsigned FRAG_KTILE_BYTES = 2 * 4 * 1024;
+__device__ __forceinline__ unsigned frag_piece_offset(const int blk, const int ks, const int K) {
+    return (((unsigned)(blk >> 2) * (unsigned)(K >> 5) + (unsigned)ks) * 4u + (unsigned)(blk & 3)) * 1024u;
 }
 
 template <int EPI> struct EpiOutIsT { static constexpr bool value = (EPI <= SLIME_EPI_BIAS_GELU_T || EPI == SLIME_EPI_BIAS_RESID_T); };
@@ -506,16 +507,17 @@ gemm_kernel(GemmArgs g) {
         a_src[i] = g.A + ((size_t)gm * g.lda) * 2 + lchunk * 16;
     }
     // the static operand comes from its row-major image (k-tile advance 128 bytes) or, when the caller passed B = NULL, from the
-    // fragment-order image alone (frag_chunk_offset: the same 16-byte chunks at permuted addresses, k-tile advance 8 KiB)
+    // fragment-order image alone (frag_piece_offset: piece q = block q >> 1, k-step q & 1, copied as it is; k-tile advance 8 KiB)
     const bool bfrag = g.B == nullptr;
     const int b_kstep = bfrag ? (int)FRAG_KTILE_BYTES : BK * 2;
     const char* b_tile0 = (bfrag ? g.Bimg : g.B) + (size_t)n0 * g.K * 2;     // BN % 64 == 0: n0 rows = n0 / 64 whole fragment tiles
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
-        const int rho = (i * NW + wave) * 8 + lrow;   // LDS row
+        const int q = i * NW + wave;                  // piece: 8 LDS rows (row-major) or one fragment of one k-step (fragment image)
+        const int rho = q * 8 + lrow;                 // LDS row
         const int nl = rho & 15;
         const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-        b_src[i] = b_tile0 + (bfrag ? (size_t)frag_chunk_offset(nphys, lchunk, g.K) : ((size_t)nphys * g.K) * 2 + lchunk * 16);
+        b_src[i] = b_tile0 + (bfrag ? (size_t)frag_piece_offset(q >> 1, q & 1, g.K) + lane * 16 : ((size_t)nphys * g.K) * 2 + lchunk * 16);
     }
 
     auto stage = [&](int s) {
@@ -540,7 +542,7 @@ gemm_kernel(GemmArgs g) {
     for (int ks = 0; ks < 2; ++ks) {
         const int sw = ((ks * 4 + (lane >> 4)) ^ (lane & 7)) << 4;
         a_off[ks] = (wm * TM + (lane & 15)) * 128 + sw;
-        b_off[ks] = A_BYTES + (wn * TN + (lane & 15)) * 128 + sw;
+        b_off[ks] = bfrag ? A_BYTES + wn * TN * 128 + ks * 1024 + lane * 16 : A_BYTES + (wn * TN + (lane & 15)) * 128 + sw;
     }
 
     f32x4 acc[MI][NI];
@@ -571,7 +573,8 @@ gemm_kernel(GemmArgs g) {
         for (int i = 0; i < B_INSTR; ++i) {
             const int rho = (i * NW + wave) * 8 + lrow, nl = rho & 15;
             const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-            soff[A_INSTR + i] = bfrag ? frag_chunk_offset(nphys, lchunk, g.K) : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+            const int q = i * NW + wave;
+            soff[A_INSTR + i] = bfrag ? frag_piece_offset(q >> 1, q & 1, g.K) + lane * 16 : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
         }
         const char* a_gbase = g.A + (size_t)m0 * g.lda * 2;
         const char* b_gbase = b_tile0;
@@ -730,6 +733,24 @@ __device__ __forceinline__ bool xcd_rows_tile(const int tiles_m, const int tiles
     return true;
 }
 static inline int xcd_rows_grid(int tiles_m, int tiles_n) { return 8 * ((tiles_m + 7) / 8) * tiles_n; }
+// BALANCED row ownership (round 5; SLIME_OPT_XCD_ROWS_DB == 2).  Whole-row-tile ownership is uneven (91 row tiles = 3 x 12 + 5 x 11) and
+// on multi-round grids the launch ends with the XCDs that own one more (round 4: fabric reads -20 %, time +2 %).  Here every XCD owns
+// q = tiles_m / 8 row tiles [x q, (x + 1) q) with all their column tiles -- walked row tile fastest, so the XCD's q activation panels
+// stay in its L2 while one weight panel after the other streams through -- and the r = tiles_m % 8 left-over row tiles' r x tiles_n
+// tiles are dealt evenly over all XCDs (column tile by column tile): work per XCD differs by at most one tile, an activation panel
+// enters one L2 (a left-over one: a few), a weight panel enters each L2 once.
+__device__ __forceinline__ bool xcd_rows_tile_balanced(const int tiles_m, const int tiles_n, int& tm, int& tn) {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3, q = tiles_m >> 3, r = tiles_m & 7;
+    const int own = q * tiles_n;
+    if (j < own) { tm = xcd * q + j % q; tn = j / q; return true; }
+    const int left = r * tiles_n, per = (left + 7) >> 3, e = (j - own) + xcd * per;
+    if (j - own >= per || e >= left) return false;
+    tm = 8 * q + e % r; tn = e / r;
+    return true;
+}
+static inline int xcd_rows_grid_balanced(int tiles_m, int tiles_n) {
+    return 8 * ((tiles_m >> 3) * tiles_n + (((tiles_m & 7) * tiles_n + 7) >> 3));
+}
 
 #define PP_BARRIER()                                   \
     do {                                               \
@@ -787,7 +808,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     // global_load_lds: half the address VGPR traffic per piece and no 64-bit VALU pointer arithmetic in the L sections;
     // the k advance is a scalar add on the base.
     const char* a_base = g.A + (size_t)m0 * g.lda * 2;
-    // static operand: row-major image, or (B = NULL) the fragment-order image alone (frag_chunk_offset; k-tile advance 8 KiB, not 128 B)
+    // static operand: row-major image, or (B = NULL) the fragment-order image alone (frag_piece_offset: every fragment copied as it is; k-tile advance 8 KiB, not 128 B)
     const bool bfrag = g.B == nullptr;
     const char* b_base = (bfrag ? g.Bimg : g.B) + (size_t)n0 * g.K * 2;
     const size_t b_kstep = bfrag ? FRAG_KTILE_BYTES : BK * 2;
@@ -811,8 +832,11 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
             const int rho = chunk * 64 + hb * 32 + sub * 8 + lrow;
             const int nl = rho & 15;
             const int nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3);
-            soff[1 + hb][j] = bfrag ? frag_chunk_offset(nphys, lchunk, g.K) : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
-            dst[1 + hb][j] = A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
+            // fragment image: half hb of 64-row tile `chunk` = blocks 4 chunk + 2 hb + (sub >> 1), k-step sub & 1 -- the same four
+            // 1-KiB pieces per (chunk, hb), each copied as it is
+            const int blk = chunk * 4 + 2 * hb + (sub >> 1);
+            soff[1 + hb][j] = bfrag ? frag_piece_offset(blk, sub & 1, g.K) + lane * 16 : (unsigned)nphys * (unsigned)g.K * 2u + lchunk * 16;
+            dst[1 + hb][j] = bfrag ? A_BYTES + blk * 2048 + (sub & 1) * 1024 : A_BYTES + (chunk * 64 + hb * 32 + sub * 8) * 128;
         }
     }
     auto issue = [&](int kind, int tile) {               // 2 pieces of `kind` for k-tile `tile`
@@ -828,7 +852,7 @@ __global__ void __launch_bounds__(512) gemm_pp_kernel(GemmArgs g) {
     for (int ks = 0; ks < 2; ++ks) {
         const int sw = ((ks * 4 + lq) ^ (lane & 7)) << 4;
         a_off[ks] = (grp * HALF + li) * 128 + sw;
-        b_off[ks] = A_BYTES + (wn * 64 + li) * 128 + sw;
+        b_off[ks] = bfrag ? A_BYTES + wn * 64 * 128 + ks * 1024 + lane * 16 : A_BYTES + (wn * 64 + li) * 128 + sw;
     }
 
     f32x4 acc[2 * MT][4];
@@ -1179,7 +1203,10 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tiles_m = (g.M + TROWS - 1) / TROWS, tiles_n = g.N / BN;
-#if SLIME_OPT_XCD_ROWS_DB
+#if SLIME_OPT_XCD_ROWS_DB == 2
+    int tm, tn;
+    if (!xcd_rows_tile_balanced(tiles_m, tiles_n, tm, tn)) return;
+#elif SLIME_OPT_XCD_ROWS_DB
     int tm, tn;
     if (!xcd_rows_tile<false>(tiles_m, tiles_n, tm, tn)) return;
 #else
@@ -1915,7 +1942,9 @@ static int launch_db_k(const GemmArgs& g, hipStream_t stream) {
     auto kern = gemm_db_kernel<T, EPI, KTAG, MI>;
     constexpr int TROWS = EPI == SLIME_EPI_BIAS_GELU_MIX_T ? BM / 2 : BM;       // tokens per tile (gemm_db_kernel)
     const int tiles_m = (g.M + TROWS - 1) / TROWS, tiles_n = g.N / 256;
-#if SLIME_OPT_XCD_ROWS_DB
+#if SLIME_OPT_XCD_ROWS_DB == 2
+    const int grid = xcd_rows_grid_balanced(tiles_m, tiles_n);
+#elif SLIME_OPT_XCD_ROWS_DB
     const int grid = xcd_rows_grid(tiles_m, tiles_n);
 #else
     const int grid = tiles_m * tiles_n;

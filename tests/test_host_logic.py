@@ -441,6 +441,34 @@ def test_xcd_owned_rows_deal_covers_every_tile_once_and_keeps_a_row_tile_in_one_
             assert deal[b + 8] == (t[0], t[1] + 1)
 
 
+@pytest.mark.parametrize("tiles_m,tiles_n", [(91, 16), (91, 12), (91, 4), (181, 16), (46, 4), (5, 4), (8, 3), (1, 1), (23, 16), (108, 16)])
+def test_balanced_xcd_row_deal_covers_every_tile_once_and_is_even(tiles_m, tiles_n):
+    """gemm.hip: xcd_rows_tile_balanced / xcd_rows_grid_balanced (round 5, SLIME_OPT_XCD_ROWS_DB == 2), restated: workgroup b runs on XCD
+    b & 7; every (row tile, column tile) exactly once, surplus workgroups exit; the XCDs' tile counts differ by at most the rounding of
+    the left-over share; a whole-owned row tile's column tiles all sit on ONE XCD."""
+    q, r = tiles_m >> 3, tiles_m & 7
+    own, left = q * tiles_n, r * tiles_n
+    per = (left + 7) >> 3
+    grid = 8 * (own + per)
+    seen, per_xcd = {}, [0] * 8
+    for b in range(grid):
+        xcd, j = b & 7, b >> 3
+        if j < own:
+            t = (xcd * q + j % q, j // q)
+        else:
+            e = (j - own) + xcd * per
+            if j - own >= per or e >= left:
+                continue
+            t = (8 * q + e % r, e // r)
+        assert t not in seen and t[0] < tiles_m and t[1] < tiles_n
+        seen[t] = xcd
+        per_xcd[xcd] += 1
+    assert len(seen) == tiles_m * tiles_n
+    assert max(per_xcd) - min(per_xcd) <= per                        # e.g. 91 x 16: 182 tiles on every XCD
+    for tm in range(8 * q):
+        assert len({seen[(tm, tn)] for tn in range(tiles_n)}) == 1
+
+
 @pytest.mark.parametrize("heads,batch,qsplit", [(16, 20, 2), (16, 5, 2), (16, 40, 2), (16, 3, 2), (16, 20, 1), (12, 7, 2), (16, 9, 3)])
 def test_attention_partner_redeal_is_a_bijection_and_pairs_share_an_xcd(heads, batch, qsplit):
     """attention.hip:attn64r_kernel's re-deal (round 4): launch-order id L -> (head, crop, query part).  Every triple exactly once;
