@@ -562,7 +562,7 @@ gemm_kernel(GemmArgs g) {
     stage_ln_rows<BM, NW * 64>(g, m0, lnrow);
     const int nk = g.K / BK;
     if constexpr (SCHED == 2) {
-        static_assert(A_INSTR + B_INSTR == 8, "counted wait below: 8 pieces per wave and stage");
+        static_assert(A_INSTR + B_INSTR == 8 || A_INSTR + B_INSTR == 4, "counted wait below: 8 (128 x 128) or 4 (64 x 64) pieces per wave and stage");
         unsigned soff[A_INSTR + B_INSTR];
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
@@ -592,8 +592,10 @@ gemm_kernel(GemmArgs g) {
         if (nk > 1) stage3(1);
         for (int kt = 0; kt < nk; ++kt) {
             // k-tile kt has landed (its pieces are older than the 8 of k-tile kt+1); every wave has finished reading k-tile kt-1
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (kt + 1 < nk) {
+                if constexpr (A_INSTR + B_INSTR == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -616,13 +618,15 @@ gemm_kernel(GemmArgs g) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = T::mfma16(bf1[j], af1[i], acc[i][j]);
-            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+            if constexpr (MI * NI >= MI + NI) {               // (the 64 x 64 tile has 8 MFMAs for 10 fragment reads: left to the compiler)
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
 #pragma unroll
-            for (int r = 0; r < MI + NI; ++r) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int r = 0; r < MI + NI; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI * NI - 2 * (MI + NI), 0);
             // the fragment reads of this k-tile must have RETURNED before the wave may enter the next barrier (the DMA issued
             // behind it overwrites this stage two tiles later: the barrier after next -- but its reads are consumed by the MFMAs
             // above, so they have)
@@ -1988,6 +1992,9 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 // rounds of workgroups are filled by running two half batches on two streams (see HipCLIPVisionModel.encode), not by
 // shrinking the tile.  Tile ids: 1 = 256x256 lock-step, 3 = 128x128, 4 = 256x256 ping-pong, 9 = 192x256 ping-pong, 10 / 11 =
 // 192x256 / 256x256 four-wave stream kernel, 12 = 128x256 direct-B kernel (needs Bf), 15 = 128x128 with a three-stage ring; diagnostic build only: 5 = persistent ping-pong, 7 = 2-phase 32x32x16 ping-pong.
+#ifndef SLIME_OPT_TILE64
+#define SLIME_OPT_TILE64 1
+#endif
 static int auto_tile(const GemmArgs& g) {
     int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
     if (tile == 4) {
@@ -2022,6 +2029,13 @@ static int auto_tile(const GemmArgs& g) {
     // (tower over 1 / 3 / 5 crops 3.12 -> 2.40 / 3.25 -> 2.75 / 3.68 -> 3.18 ms; beyond one workgroup per CU the two-stage form's second
     // resident workgroup is worth more: 9 crops 4.78 vs 5.10 -- tools/rank_shapes.py, profiles/r03_small_batch_latency_c.txt)
     if (tile == 3 && (long)((g.M + 127) / 128) * (g.N / 128) <= num_cus()) tile = 15;
+    // ... and grids that leave HALF the CUs without even a 128 x 128 workgroup (one to three crops: BASELINE config 1, the smallest rank
+    // shards) run 64 x 64 tiles on the same three-stage ring (tile 18, round 5): four times the workgroups, and a wave's chain per k-tile
+    // is 8 MFMAs instead of 32 -- these launches are bound by that dependent chain (fc2 at one crop: 40 workgroups x 64 k-tiles), not by
+    // throughput.  Same k order per accumulator, same epilogue: bit-identical to every other tile.
+#if SLIME_OPT_TILE64
+    if (tile == 15 && (long)((g.M + 127) / 128) * (g.N / 128) * 2 <= num_cus()) tile = 18;
+#endif
     return tile;
 }
 
@@ -2050,7 +2064,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
     if (!g.B && (tile == 5 || tile == 6 || tile == 7 || tile == 8)) tile = 4;        // persistent / 32x32 ping-pong variants stage row-major B only
-    if ((tile == 1 || (tile >= 4 && tile != 15)) && g.N % 256 != 0) tile = 3;
+    if ((tile == 1 || (tile >= 4 && tile != 15 && tile != 18)) && g.N % 256 != 0) tile = 3;
     if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T || EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN)) tile = 4;     // the 32x32 variant has neither epilogue
@@ -2072,6 +2086,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     // kernel (never picked by auto_tile when a fragment image exists) is replaced by the direct-B kernel, or the ping-pong one
     if (!g.B && (tile == 10 || tile == 11)) tile = g.Bf ? 12 : 4;
     if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
+    if (tile == 18) return launch_cfg<T, 64, 64, 4, 1, EPI, 2>(g, stream);        // 64 x 64, three-stage ring (the smallest grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
@@ -2113,6 +2128,7 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
     else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
+    else if (tile == 18) snprintf(out, out_len, "gemm_kernel<%s, 64, 64, 4, 1, %d, 2>", t, epilogue);
     else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, %d>", t, epilogue, tile == 15 ? 2 : 1);
     return SLIME_OK;
 }

@@ -117,6 +117,8 @@ def gemm(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor
     EPI_BIAS_RESID_T (out = T(a @ w.T + bias + resid), out may be resid)."""
     lib = _lib.load()
     M, K = a.shape
+    if w is None and w_frag is None:
+        raise ValueError("gemm: the static operand is missing (row-major w, its fragment-order image w_frag, or both)")
     N = (w if w is not None else w_frag).shape[0]        # w = None: the fragment-order image alone (slime_gemm_b_frag_usable)
     if out is None:
         odt = a.dtype if (epilogue <= _lib.EPI_BIAS_GELU_T or epilogue == _lib.EPI_BIAS_RESID_T) else torch.float32

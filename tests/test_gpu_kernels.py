@@ -36,7 +36,7 @@ def _rand(shape, dtype, dev, seed, scale=1.0):
 
 # ------------------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (3, 1), (3, 0), (0, 1), (4, 1), (5, 1), (7, 1), (9, 1), (10, 1), (11, 1), (15, 1)])
+@pytest.mark.parametrize("tile,sched", [(1, 1), (1, 0), (3, 1), (3, 0), (0, 1), (4, 1), (5, 1), (7, 1), (9, 1), (10, 1), (11, 1), (15, 1), (18, 1)])
 @pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128)])
 def test_gemm_epilogues(dev, dtype, tile, sched, M, N, K):
     """Every tile / kernel variant (forced through the DIAGNOSTIC build's hook) x every epilogue vs fp32 torch."""
@@ -492,7 +492,7 @@ def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,tile", [(11540, 1024, 4096, 0), (11540, 1024, 1024, 0), (2885, 1024, 4096, 0), (577, 1024, 1024, 0),
                                         (1731, 1024, 1024, 4), (300, 768, 640, 3), (2308, 512, 128, 15), (1731, 1024, 1024, 12),
-                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 1)])
+                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 1), (1731, 1024, 1024, 18), (577, 1024, 4096, 18)])
 def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
     """SLIME_EPI_BIAS_RESID_SPLIT_LN (round 5): the residual update on a 2 x 16-bit split stream.  Against fp32 torch on the same
     operands: hi' = T(c) EXACTLY for c = the kernel's own fp32 result (checked through the fp32 epilogue, which computes the same c
@@ -542,7 +542,8 @@ def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
 @pytest.mark.parametrize("M,N,K,tile", [(11540, 1024, 4096, 0), (11540, 4096, 1024, 0), (2885, 1024, 4096, 0), (577, 3072, 1024, 0), (577, 1024, 4096, 0),
                                         (4608, 1024, 1024, 0), (300, 768, 640, 0), (77, 256, 64, 0), (2308, 512, 128, 0), (1731, 1024, 1024, 4),
                                         (1731, 1024, 1024, 9), (1731, 1024, 1024, 3), (1731, 1024, 1024, 15), (1731, 1024, 1024, 1),
-                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 5), (1731, 1024, 1024, 7)])
+                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 5), (1731, 1024, 1024, 7), (1731, 1024, 1024, 18),
+                                        (300, 768, 640, 18)])
 def test_gemm_from_fragment_image_alone(dev, dtype, M, N, K, tile):
     """ABI 5: with B = NULL every kernel the dispatch can reach takes the static operand from the fragment-order
     image -- the LDS-staged kernels DMA the same 16-byte chunks from permuted addresses -- and the result is BIT-IDENTICAL to the
@@ -567,8 +568,30 @@ def test_gemm_from_fragment_image_alone(dev, dtype, M, N, K, tile):
             assert torch.equal(h1, h2) and torch.equal(x1, x2) and torch.equal(s1, s2)
         finally:
             lib.slime_gemm_force_tile(0)
-    with pytest.raises(_lib.SlimeHipError, match="null pointer"):
+    with pytest.raises(ValueError, match="static operand"):
         ops.gemm(a, None, bias, _lib.EPI_BIAS_F32, out=torch.empty((M, N), dtype=torch.float32, device=dev))
+    g = _lib.GemmArgs(A=a.data_ptr(), lda=K, bias=bias.data_ptr(), C=h0.data_ptr(), ldc=N, M=M, N=N, K=K, dtype=ops.dtype_code(dtype),
+                      epilogue=_lib.EPI_BIAS_F32)
+    import ctypes
+    assert _lib.load().slime_gemm_ex(ctypes.byref(g), 0) == -1 and b"null pointer" in _lib.load().slime_last_error()     # C ABI: B and B_frag both NULL
+
+
+def test_small_grid_dispatch_uses_64_row_tiles(dev):
+    """auto_tile (round 5): grids that leave half the CUs without a 128 x 128 workgroup -- one crop's GEMMs -- take the 64 x 64 ring
+    tile; from one workgroup per two CUs on, the 128 x 128 kernels as before; and the tile is bit-invisible (one crop inside a batch of
+    three equals the crop alone: test_tower_batch_invariance covers the tower, this the GEMM)."""
+    from slime_amd import ops, _lib
+    dt = torch.bfloat16
+    assert "64, 64, 4, 1" in ops.gemm_kernel_name(577, 1024, 4096, dt, _lib.EPI_BIAS_F32)
+    assert "64, 64, 4, 1" in ops.gemm_kernel_name(577, 3072, 1024, dt, _lib.EPI_BIAS_T)
+    assert "128, 128, 2, 2" in ops.gemm_kernel_name(2885, 1024, 1024, dt, _lib.EPI_BIAS_F32)
+    a = _rand((3 * 577, 1024), dt, dev, 1)
+    w = _rand((1024, 1024), dt, dev, 2, 1 / 32)
+    bias = _rand((1024,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    big = ops.gemm(a, None, bias, _lib.EPI_BIAS_QUICKGELU_T, w_frag=wf)
+    one = ops.gemm(a[577:1154].contiguous(), None, bias, _lib.EPI_BIAS_QUICKGELU_T, w_frag=wf)
+    assert torch.equal(big[577:1154], one)
 
 
 def test_gather_rows_split(dev):

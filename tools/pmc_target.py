@@ -38,14 +38,4 @@ for _ in range(3):
                                            S * N, N, o.data_ptr(), S * HQ * 128, HQ * 128, B, HQ, HKV, 128, S, None, None, _lib.BF16,
                                            torch.cuda.current_stream().cuda_stream))
 torch.cuda.synchronize()
-# round 2's CLIP attention kernel (attn64r: still the fp16 path) and the cut launch form of attn32, 20 crops (diagnostic build)
-if os.path.exists(_lib.DIAG_LIB_PATH):
-    with _lib.diag() as dl:
-        x = torch.randn(n, 577, 3072, device=dev).to(dt); x[..., :1024] *= 0.125
-        for var in (7, 4):
-            dl.slime_attention_set_variant(var)
-            for _ in range(4):
-                ops.attention(x[..., :1024], x[..., 1024:2048], x[..., 2048:], 16, 64)
-        dl.slime_attention_set_variant(0)
-    torch.cuda.synchronize()
 print("pmc target done")

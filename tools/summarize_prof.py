@@ -7,8 +7,8 @@ def load_counters(d):
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            if any(k in name for k in ("gemm", "attn", "prefill32", "layernorm", "embed_prenorm", "rope", "im2col", "gather_rows")):
-                key = name.replace("void ", "").split("(")[0]
+            if any(k in name for k in ("gemm", "attn", "prefill32", "layernorm", "patch_embed", "rope", "gather_rows")):
+                key = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
                 if ("prefill32" in key or "attn32" in key) and r.get("Grid_Size"):
                     key += f" [grid {r['Grid_Size']}]"       # one row per launch shape (8 x 1216 and 1 x 9280; cut and uncut)
                 rows[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -41,7 +41,12 @@ def main():
         if "WRITE_SIZE" in o:
             o["hbm_write_bytes"] = round(o["WRITE_SIZE"] * 1024)
     os.makedirs("profiles", exist_ok=True)
+    # which build the passes ran on (the GPU box has no .git: the run script hands the commit over in SLIME_GIT_HEAD); bench.py prints
+    # it as roofline.traffic_head next to the traffic figure it reads from this file
+    out["_meta"] = {"git_head": os.environ.get("SLIME_GIT_HEAD", "unknown"), "target": "tools/pmc_target.py",
+                    "passes": ["prof_pmc_sq", "prof_pmc_fetch", "prof_pmc_write"]}
     json.dump(out, open(f"profiles/{tag}_pmc_kernels.json", "w"), indent=1, sort_keys=True)
+    del out["_meta"]
     # derived figures per kernel: MFMA-busy fraction of the chip's SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over
     # SIMDs; GRBM_GUI_ACTIVE x 128 matches the sum at 100 % on this part), LDS conflict share, where the wave cycles went
     summ = {}
