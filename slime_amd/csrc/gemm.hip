@@ -2033,7 +2033,9 @@ static int auto_tile(const GemmArgs& g) {
     // shards) run 64 x 64 tiles on the same three-stage ring (tile 18, round 5): four times the workgroups, and a wave's chain per k-tile
     // is 8 MFMAs instead of 32 -- these launches are bound by that dependent chain (fc2 at one crop: 40 workgroups x 64 k-tiles), not by
     // throughput.  Same k order per accumulator, same epilogue: bit-identical to every other tile.
-#if SLIME_OPT_TILE64
+#if SLIME_OPT_TILE64 == 2      // measured alternative: every grid of at most one 128 x 128 workgroup per CU (tools/small_latency_ab.py)
+    if (tile == 15) tile = 18;
+#elif SLIME_OPT_TILE64
     if (tile == 15 && (long)((g.M + 127) / 128) * (g.N / 128) * 2 <= num_cus()) tile = 18;
 #endif
     return tile;

@@ -310,11 +310,11 @@ def test_gather_chunk_cost_model():
     from slime_amd import dist as D
     prof = D.tower_latency_profile()                                     # slime_amd/data/tower_latency_mi355x_vitl336_bf16.json
     T = prof["ms"]
-    assert prof["device"] == "MI355X" and prof["dtype"] == "bf16" and T[1] == 2.40 and T[40] == 15.22
+    assert prof["device"] == "MI355X" and prof["dtype"] == "bf16" and T[1] == 1.87 and T[40] == 14.44
     for n in (1, 5, 9, 17, 34, 40, 68):
         assert abs(D.tower_ms(n) - (T[n] if n in T else D.tower_ms(n))) < 1e-9
     assert D.tower_ms(0) == 0.0 and D.tower_ms(11) == pytest.approx((T[10] + T[12]) / 2)
-    assert D.tower_ms(60) == pytest.approx(T[40] + 0.334 * 20)
+    assert D.tower_ms(60) == pytest.approx(T[40] + prof["ms_per_crop_beyond"] * 20)
     # the curve is a profile of ONE device / tower / dtype; for anything else the policy decides nothing (chunk 0)
     assert D.profile_applies(prof, "AMD Instinct MI355X", "CLIP-ViT-L/14-336", "bf16") and D.profile_applies(prof)
     assert not D.profile_applies(prof, "AMD Instinct MI300X") and not D.profile_applies(prof, None, None, "fp16")
