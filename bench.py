@@ -59,7 +59,7 @@ PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARC
 # What the matrix pipes deliver on THIS chip with fresh random bf16 operands in every MFMA and nothing else in the stream (the chip
 # clocks to its 1400 W cap: profiles/r04_ps_ablation.txt, profiles/r04_power_cap.txt).  Reported beside `peak`, never instead of it.
 MFMA_STREAM_AT_POWER_CAP_TFLOPS = 1616.0
-PMC_FILE = "r04_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
+PMC_FILE = "r05_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
 
 CONFIGS = {                            # images per step, local crops per image, local grid
     2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
