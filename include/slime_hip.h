@@ -91,7 +91,10 @@ int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 /* Epilogue SLIME_EPI_BIAS_GELU_MIX_T (round 4; needs B_frag, N % 256 == 0): ONE launch computes projection[0] + GELU of BOTH experts'
  * rows of a token (A = T(x), A2 = attn(x): a workgroup's 128-row tile is 64 rows of A and the same 64 rows of A2, so a lane holds
  * both results of a token) and stores their gate mix, rounded once: C[t, :] = T(g0 a0 + g1 a1), M = tokens.  projection[2] applied to
- * C equals the mix of the two expert outputs (GatedBlock.forward, projector/builder.py:190-206) up to 1e-6 |b2|, see slime_gate_premix. */
+ * C equals the mix of the two expert outputs (GatedBlock.forward, projector/builder.py:190-206) up to 1e-6 |b2|, see slime_gate_premix.
+ * Which of the two forms slime_gated_forward / slime_adapter_forward take depends on the descriptor: with w1_frag (hidden % 256 == 0) the
+ * mix happens here, in fp32, rounded to T once; without it slime_gate_premix mixes the already-rounded hidden rows (two roundings) --
+ * the outputs of the two forms differ in the last bit of T for the same inputs.  Eval mode only (no noisy gating, builder.py:150-157). */
 
 /* A STATIC B operand (nn.Linear weights: every GEMM of this path) can additionally be handed over in MFMA-fragment order:
  * out[((t*(K/32) + s)*4 + f)*64 + lane] (16-byte units) = B[64t + 32(f>>1) + 8((lane&15)>>2) + 4(f&1) + (lane&3)][32s + 8(lane>>4) .. +8].
