@@ -86,6 +86,9 @@ typedef struct {
     const void* A2;              /* epilogue BIAS_GELU_MIX_T: the second expert's operand rows T [M, lda], else NULL  */
     const float* mix_gates;      /* epilogue BIAS_GELU_MIX_T: fp32 [M, 2] gate pair per row (slime_gate_weights)      */
     void* lo16; int ldlo;        /* epilogue BIAS_RESID_SPLIT_LN: lower half of the split residual stream, T [M, ldlo], read and written in place */
+    const int* row_map;          /* optional (epilogues BIAS_T / BIAS_QUICKGELU_T / BIAS_GELU_T / BIAS_F32 without the LayerNorm fold): output row r
+                                  * is stored at C row row_map[r] (device int32 [M], a permutation / scatter into a larger buffer) instead of r:
+                                  * lets a GEMM write straight into its consumer's layout (the adapter's token buffer: no merge pass)   */
 } slime_gemm_args;
 int slime_gemm_ex(const slime_gemm_args* args, void* stream);
 /* Epilogue SLIME_EPI_BIAS_GELU_MIX_T (round 4; needs B_frag, N % 256 == 0): ONE launch computes projection[0] + GELU of BOTH experts'

@@ -48,7 +48,7 @@ class GemmArgs(C.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
                 ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int),
-                ("A2", c_void_p), ("mix_gates", c_void_p), ("lo16", c_void_p), ("ldlo", c_int)]
+                ("A2", c_void_p), ("mix_gates", c_void_p), ("lo16", c_void_p), ("ldlo", c_int), ("row_map", c_void_p)]
 
 
 class ResamplerDesc(C.Structure):

@@ -452,7 +452,12 @@ extern "C" int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resamp
 // ------------------------------------------------------------------------------------------------
 // Fused adapter (GatedBlock on the global crops + post_qformer/MLP/merge on the local crops)
 // ------------------------------------------------------------------------------------------------
-struct AdapterPlan { size_t xg32, xl32, stack, e, mlp, res, gates, total; long rows_g, rows_l, rows_all; int segs_g; };
+#ifndef SLIME_OPT_ADAPTER_DIRECT
+#define SLIME_OPT_ADAPTER_DIRECT 1      // 0 = round 4's fp32 rows + two merge_rows passes (tools/build_variants.sh A/B)
+#endif
+int adapter_row_map_launch(int* map, long rows_g, int P, long rows_l, long per_image_local, int g, int nw, int merge, long out_image_stride,
+                           void* stream);                                   // rowwise.hip (internal)
+struct AdapterPlan { size_t xg32, xl32, stack, e, mlp, res, gates, rmap, total; long rows_g, rows_l, rows_all; int segs_g; };
 static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_desc* attn, const slime_resampler_desc* post,
                                 int n_images, int n_local, int learnable_gated) {
     AdapterPlan p{};
@@ -472,6 +477,7 @@ static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_d
     if (post && n_local > 0) { const size_t r2 = res_plan(post, n_images * n_local).total; if (r2 > res) res = r2; }
     p.res = take(res);
     p.gates = take((size_t)p.rows_g * 2 * sizeof(float));
+    p.rmap = take((size_t)(p.rows_g + p.rows_l) * sizeof(int));
     p.total = align_up(off, 256);
     return p;
 }
@@ -540,6 +546,25 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
     const MlpPlan mp = mlp_plan(mlp, (int)p.rows_all);
     char* mid = w + p.mlp + mp.mid;
     long e_glob = 0, e_local = seg_local;                       // rows of e
+    // Round 5: projection[2] stores every output row straight into the token buffer (slime_gemm_args.row_map: global rows to rows
+    // [0, P) of their image, local rows to their raster position behind them) in the output dtype -- no fp32 rows `e`, no merge
+    // passes (two launches, 151 MB written + read back per 8 x (1+4) step).  The same values, rounded once by the same RNE pack as the
+    // merge kernel's: bit-identical to the per-module sequence.  Other output dtypes (a 16-bit type that is not the operand type) keep
+    // the fp32 rows + merge path.
+    const bool direct = SLIME_OPT_ADAPTER_DIRECT && (out_dtype == SLIME_F32 || out_dtype == dt);
+    int* rmap = (int*)(w + p.rmap);
+    if (direct) {
+        SLIME_REQUIRE((long)n_images * out_image_stride < (1L << 31), "adapter: token buffer too large for the 32-bit row map");
+        TRY(adapter_row_map_launch(rmap, p.rows_g, P, p.rows_l, post ? (long)n_local * post->n_query : 1, g > 0 ? g : 1, nw > 0 ? nw : 1, merge,
+                                   out_image_stride, stream));
+    }
+    auto projection2 = [&](const void* A, int rows) -> int {     // rows = [global | local] rows of the hidden activations
+        slime_gemm_args a{};
+        a.A = A; a.lda = H; a.B = mlp->w2; a.B_frag = mlp->w2_frag; a.bias = mlp->b2; a.M = rows; a.N = H; a.K = H; a.dtype = dt;
+        if (direct) { a.C = out; a.ldc = H; a.row_map = rmap; a.epilogue = out_dtype == SLIME_F32 ? SLIME_EPI_BIAS_F32 : SLIME_EPI_BIAS_T; }
+        else { a.C = e; a.ldc = H; a.epilogue = SLIME_EPI_BIAS_F32; }
+        return slime_gemm_ex(&a, stream);
+    };
     if (learnable_gated < 0) {
         char* mixed = mid + (size_t)seg_attn * H * 2;
         if (mix_in_gemm(mlp)) {
@@ -555,16 +580,18 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
             TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
             TRY(slime_gate_premix(xg32, D, w_gate, mid + (size_t)seg_x * H * 2, mixed, mixed, dt, (int)p.rows_g, H, stream));
         }
-        TRY(gemm_w(mixed, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)(p.rows_g + p.rows_l), H, H, dt, SLIME_EPI_BIAS_F32, stream));
+        TRY(projection2(mixed, (int)(p.rows_g + p.rows_l)));
         e_local = p.rows_g;
     } else {
         TRY(gemm_w(stack, D, mlp->w1, mlp->w1_frag, mlp->b1, mid, H, (int)p.rows_all, H, D, dt, SLIME_EPI_BIAS_GELU_T, stream));
-        TRY(gemm_w(mid, H, mlp->w2, mlp->w2_frag, mlp->b2, e, H, (int)p.rows_all, H, H, dt, SLIME_EPI_BIAS_F32, stream));
+        TRY(projection2(mid, (int)p.rows_all));
     }
-    // global tokens -> rows [0, P) of every image: flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)
-    TRY(slime_merge_rows_batched(e + (size_t)e_glob * H, P, out, out_dtype, out_image_stride, 0, n_images, P, 1, 1, H, 0, stream));
-    if (post)
-        TRY(slime_merge_rows_batched(e + (size_t)e_local * H, (long)n_local * post->n_query, out, out_dtype, out_image_stride, P,
-                                     n_images, nw, nh, g, H, merge, stream));
+    if (!direct) {
+        // global tokens -> rows [0, P) of every image: flat cast-copy of P rows per image (nw = P, nh = g = 1, merge = 0)
+        TRY(slime_merge_rows_batched(e + (size_t)e_glob * H, P, out, out_dtype, out_image_stride, 0, n_images, P, 1, 1, H, 0, stream));
+        if (post)
+            TRY(slime_merge_rows_batched(e + (size_t)e_local * H, (long)n_local * post->n_query, out, out_dtype, out_image_stride, P,
+                                         n_images, nw, nh, g, H, merge, stream));
+    }
     return SLIME_OK;
 }

@@ -381,13 +381,15 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
                     packed[i][p][2] = T::pack2(acc[i][2 * p + 1][0], acc[i][2 * p + 1][1]);
                     packed[i][p][3] = T::pack2(acc[i][2 * p + 1][2], acc[i][2 * p + 1][3]);
                 }
+            // g.row_map (optional): the row is stored where its consumer wants it (the adapter's token buffer) instead of at `row`
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int row = row_base + i * 16;
                 if (in_range(row)) {
+                    const size_t orow = g.row_map ? (size_t)g.row_map[row] : (size_t)row;
 #pragma unroll
                     for (int p = 0; p < NP; ++p)
-                        st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + ((size_t)row * g.ldc + col_base + 32 * p) * 2), packed[i][p]);
+                        st_stream(reinterpret_cast<u32x4*>(reinterpret_cast<char*>(g.C) + (orow * g.ldc + col_base + 32 * p) * 2), packed[i][p]);
                 }
             }
         } else {
@@ -396,9 +398,10 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
             for (int i = 0; i < MI; ++i) {
                 const int row = row_base + i * 16;
                 if (in_range(row)) {
+                    const size_t orow = g.row_map ? (size_t)g.row_map[row] : (size_t)row;
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
-                        float* o = C + (size_t)row * g.ldc + col_base + 32 * p;
+                        float* o = C + orow * g.ldc + col_base + 32 * p;
                         st_stream(reinterpret_cast<f32x4*>(o), acc[i][2 * p]);
                         st_stream(reinterpret_cast<f32x4*>(o + 4), acc[i][2 * p + 1]);
                     }
@@ -2065,7 +2068,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
         for (int i = 0; i < g_rules; ++i)
             if (g_rule_n[i] == g.N && g_rule_k[i] == g.K) tile = g_rule_tile[i];
     if (tile == 2) tile = 1;
-    if (!g.B && (tile == 5 || tile == 6 || tile == 7 || tile == 8)) tile = 4;        // persistent / 32x32 ping-pong variants stage row-major B only
+    if ((!g.B || g.row_map) && (tile == 5 || tile == 6 || tile == 7 || tile == 8)) tile = 4;   // persistent / 32x32 ping-pong variants: row-major B only, no row map
     if ((tile == 1 || (tile >= 4 && tile != 15 && tile != 18)) && g.N % 256 != 0) tile = 3;
     if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
@@ -2157,6 +2160,11 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     if (a->epilogue == SLIME_EPI_BIAS_RESID_F32_LN)
         SLIME_REQUIRE(a->x16 && a->stats_out && a->ldx >= N && a->ldx % 8 == 0 && ((uintptr_t)a->x16 % 16) == 0 &&
                       ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0, "gemm: BIAS_RESID_F32_LN needs x16 [M, ldx] and stats_out [M, N/64, 2]");
+    if (a->row_map)
+        SLIME_REQUIRE(!a->ln_stats && ((uintptr_t)a->row_map % 4) == 0 &&
+                      (a->epilogue == SLIME_EPI_BIAS_T || a->epilogue == SLIME_EPI_BIAS_QUICKGELU_T || a->epilogue == SLIME_EPI_BIAS_GELU_T ||
+                       a->epilogue == SLIME_EPI_BIAS_F32),
+                      "gemm: row_map goes with the plain T / fp32 epilogues (BIAS_T, BIAS_QUICKGELU_T, BIAS_GELU_T, BIAS_F32; no LayerNorm fold)");
     if (a->epilogue == SLIME_EPI_BIAS_RESID_SPLIT_LN)
         SLIME_REQUIRE(a->lo16 && a->stats_out && a->ldlo >= N && a->ldlo % 8 == 0 && ((uintptr_t)a->lo16 % 16) == 0 &&
                       ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0 && a->lo16 != a->C,
@@ -2172,7 +2180,7 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
                a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
                frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr, (const char*)a->A2, a->mix_gates,
-               (char*)a->lo16, a->ldlo, (const char*)a->B_frag};
+               (char*)a->lo16, a->ldlo, (const char*)a->B_frag, a->row_map};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);

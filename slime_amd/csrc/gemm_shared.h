@@ -29,6 +29,8 @@ struct GemmArgs {
     // the fragment-order image whatever the shape (Bf is set only where the direct-B kernel is eligible): the LDS-staged kernels
     // DMA from it when B == NULL
     const char* Bimg;
+    // optional scatter of the output rows (generic T / fp32 epilogues): row r is stored at C row row_map[r]
+    const int* row_map;
 };
 
 // (sum x, sum x^2) of a K-wide row -> (rstd, -mu rstd).  One shared definition with the operations written out (no contraction left

@@ -370,6 +370,40 @@ extern "C" int slime_merge_rows_batched(const float* in, long in_image_stride, v
     return SLIME_OK;
 }
 
+// Row map of the fused adapter (round 5): GEMM row r of projection[2]'s output [global rows of every image | local rows of every image]
+// -> row of the [images, out_image_stride, H] token buffer -- the arithmetic of the two merge_rows launches above as an int32 table,
+// so that the GEMM's epilogue stores every row where it belongs (slime_gemm_args.row_map) and the fp32 round trip + merge pass go.
+__global__ void __launch_bounds__(256) adapter_row_map_kernel(int* map, long rows_g, int P, long rows_l, long per_image_local, int g, int nw,
+                                                              int merge, long out_image_stride) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows_g + rows_l) return;
+    long dst;
+    if (r < rows_g) {
+        dst = (r / P) * out_image_stride + r % P;
+    } else {
+        const long q = r - rows_g, b = q / per_image_local, rr = q % per_image_local;
+        long d = rr;
+        if (merge) {
+            const int qx = (int)(rr % g), qy = (int)((rr / g) % g), k = (int)(rr / ((long)g * g));
+            const int gx = k % nw, gy = k / nw;
+            d = ((long)(gy * g + qy) * nw + gx) * g + qx;
+        }
+        dst = b * out_image_stride + P + d;
+    }
+    map[r] = (int)dst;
+}
+
+// internal (not part of the C ABI: the version script keeps it local)
+int adapter_row_map_launch(int* map, long rows_g, int P, long rows_l, long per_image_local, int g, int nw, int merge, long out_image_stride,
+                           void* stream) {
+    const long total = rows_g + rows_l;
+    if (total <= 0) return SLIME_OK;
+    hipLaunchKernelGGL(adapter_row_map_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, map, rows_g, P, rows_l,
+                       per_image_local, g, nw, merge, out_image_stride);
+    SLIME_CHECK_LAUNCH("adapter_row_map");
+    return SLIME_OK;
+}
+
 extern "C" int slime_merge_rows(const float* in, void* out, int out_dtype, long dst_row0, int nw, int nh, int g,
                                 int C, int merge, void* stream) {
     return slime_merge_rows_batched(in, 0, out, out_dtype, 0, dst_row0, 1, nw, nh, g, C, merge, stream);

@@ -112,9 +112,11 @@ def packed_weight_bytes(*packs) -> int:
 
 
 def gemm(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], epilogue: int,
-         out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, w_frag: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+         row_map: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(a @ w.T + bias); a [M,K] T, w [N,K] T, bias fp32 [N]; w_frag = pack_b_frag(w) (optional); resid T [M,N] for
-    EPI_BIAS_RESID_T (out = T(a @ w.T + bias + resid), out may be resid)."""
+    EPI_BIAS_RESID_T (out = T(a @ w.T + bias + resid), out may be resid); row_map int32 [M] (device): row r of the result is stored
+    at out[row_map[r]] (``out`` given, with at least max(row_map) + 1 rows; plain T / fp32 epilogues)."""
     lib = _lib.load()
     M, K = a.shape
     if w is None and w_frag is None:
@@ -125,7 +127,7 @@ def gemm(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor
         out = torch.empty((M, N), dtype=odt, device=a.device)
     g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(out), ldc=out.stride(0), M=M, N=N, K=K,
                       dtype=dtype_code(a.dtype), epilogue=epilogue, B_frag=_ptr(w_frag), resid=_ptr(resid),
-                      ldr=resid.stride(0) if resid is not None else 0)
+                      ldr=resid.stride(0) if resid is not None else 0, row_map=_ptr(row_map))
     _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return out
 

@@ -595,6 +595,43 @@ def test_small_grid_dispatch_uses_64_row_tiles(dev):
     assert torch.equal(big[577:1154], one)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,tile", [(9216, 4096, 4096, 0), (300, 768, 640, 0), (577, 1024, 1024, 0), (1731, 1024, 1024, 4), (1731, 1024, 1024, 3),
+                                        (1731, 1024, 1024, 12), (1731, 1024, 1024, 11), (1731, 1024, 1024, 15), (577, 1024, 1024, 18)])
+def test_gemm_row_map_scatter(dev, dtype, M, N, K, tile):
+    """slime_gemm_args.row_map (round 5): output row r is stored at C row row_map[r] -- a scatter into a larger buffer, bit-identical to
+    the plain result row by row, untouched rows stay untouched; plain T / fp32 epilogues on every kernel family (the adapter's
+    projection[2] writes the token buffer this way: shape 9216 x 4096 x 4096)."""
+    from slime_amd import ops, _lib
+    a = _rand((M, K), dtype, dev, 1)
+    w = _rand((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rand((N,), torch.float32, dev, 3)
+    wf = ops.pack_b_frag(w)
+    g = torch.Generator().manual_seed(7)
+    rows_out = M + 37
+    rmap = torch.randperm(rows_out, generator=g)[:M].to(torch.int32).to(dev)
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(tile)
+        try:
+            for epi, odt in ((_lib.EPI_BIAS_T, dtype), (_lib.EPI_BIAS_GELU_T, dtype), (_lib.EPI_BIAS_F32, torch.float32)):
+                plain = ops.gemm(a, w, bias, epi, w_frag=wf)
+                out = torch.full((rows_out, N), 7.0, dtype=odt, device=dev)
+                ops.gemm(a, None, bias, epi, out=out, w_frag=wf, row_map=rmap)
+                assert torch.equal(out[rmap.long()], plain), epi
+                untouched = torch.ones(rows_out, dtype=torch.bool, device=dev)
+                untouched[rmap.long()] = False
+                assert bool((out[untouched] == 7.0).all()), epi
+        finally:
+            lib.slime_gemm_force_tile(0)
+    x16 = _rand((M, K), dtype, dev, 5)
+    st = torch.zeros((M, K // 64, 2), dtype=torch.float32, device=dev)
+    gargs = _lib.GemmArgs(A=x16.data_ptr(), lda=K, B_frag=wf.data_ptr(), bias=bias.data_ptr(), C=plain.data_ptr(), ldc=N, M=M, N=N, K=K,
+                          dtype=ops.dtype_code(dtype), epilogue=_lib.EPI_BIAS_T, ln_stats=st.data_ptr(), ln_groups=K // 64,
+                          ln_colsum=bias.data_ptr(), ln_eps=1e-5, row_map=rmap.data_ptr())
+    import ctypes
+    assert _lib.load().slime_gemm_ex(ctypes.byref(gargs), 0) == -1 and b"row_map" in _lib.load().slime_last_error()
+
+
 def test_gather_rows_split(dev):
     """slime_gather_rows_split: the tower's final feature_select / cast from the 2 x 16-bit split residual stream."""
     from slime_amd import _lib
