@@ -307,10 +307,16 @@ extern "C" size_t slime_resampler_workspace_bytes(const slime_resampler_desc* d,
     return res_plan(d, n).total;
 }
 
-extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const float* x, int ldx, int n, float* out_f32,
-                                       void* out_t, void* ws, size_t ws_bytes, void* stream) {
+int layernorm_crops_launch(const void* feats, int dtype, int P, int period, int first, int per_image, int images, int D, const float* w,
+                           const float* b, float eps, void* out_t, void* out_t2, const float* add, int add_period, void* stream);   // rowwise.hip (internal)
+
+// crops != nullptr (fused adapter, round 5): the input rows are the selected crops of the tower's T features, read by the first
+// LayerNorm directly (no fp32 copy of them); otherwise x fp32 [n, n_kv, dim]
+struct ResCrops { const void* feats; int period, first, per_image, images; };
+static int resampler_run(const slime_resampler_desc* d, const float* x, int ldx, const ResCrops* crops, int n, float* out_f32,
+                         void* out_t, void* ws, size_t ws_bytes, void* stream) {
     TRY(resampler_validate(d));
-    SLIME_REQUIRE(x && n > 0 && ldx >= d->dim, "resampler: bad input");
+    SLIME_REQUIRE((x || crops) && n > 0 && (crops || ldx >= d->dim), "resampler: bad input");
     SLIME_REQUIRE(out_f32 || out_t, "resampler: no output requested");
     const ResPlan p = res_plan(d, n);
     if (!ws || ws_bytes < p.total || ((uintptr_t)ws % 256) != 0) {
@@ -320,8 +326,12 @@ extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const floa
     char* w = (char*)ws;
     const int D = d->dim, Rk = n * d->n_kv, Rq = n * d->n_query, dh = D / d->heads, dt = d->dtype;
     // x = ln_kv(x); K input = x + pos (sampler.py:158,164); V input = x
-    TRY(slime_layernorm(x, ldx, Rk, D, d->ln_kv_w, d->ln_kv_b, d->eps, 1, nullptr, w + p.xn, w + p.xk, d->pos_k,
-                        d->n_kv, dt, stream));
+    if (crops)
+        TRY(layernorm_crops_launch(crops->feats, dt, d->n_kv, crops->period, crops->first, crops->per_image, crops->images, D, d->ln_kv_w,
+                                   d->ln_kv_b, d->eps, w + p.xn, w + p.xk, d->pos_k, d->n_kv, stream));
+    else
+        TRY(slime_layernorm(x, ldx, Rk, D, d->ln_kv_w, d->ln_kv_b, d->eps, 1, nullptr, w + p.xn, w + p.xk, d->pos_k,
+                            d->n_kv, dt, stream));
     TRY(gemm_w(w + p.xk, D, d->w_k, d->w_k_frag, d->b_k, w + p.kp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
     TRY(gemm_w(w + p.xn, D, d->w_v, d->w_v_frag, d->b_v, w + p.vp, D, Rk, D, D, dt, SLIME_EPI_BIAS_T, stream));
     TRY(slime_attention(d->q_proj, 0, D, w + p.kp, (long)d->n_kv * D, D, w + p.vp, (long)d->n_kv * D, D, w + p.ctx,
@@ -330,6 +340,12 @@ extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const floa
     TRY(slime_layernorm((const float*)(w + p.o32), D, Rq, D, d->ln_post_w, d->ln_post_b, d->eps, 1, out_f32, out_t,
                         nullptr, nullptr, 0, dt, stream));
     return SLIME_OK;
+}
+
+extern "C" int slime_resampler_forward(const slime_resampler_desc* d, const float* x, int ldx, int n, float* out_f32,
+                                       void* out_t, void* ws, size_t ws_bytes, void* stream) {
+    SLIME_REQUIRE(x, "resampler: bad input");
+    return resampler_run(d, x, ldx, nullptr, n, out_f32, out_t, ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,7 +485,7 @@ static AdapterPlan adapter_plan(const slime_mlp_desc* m, const slime_resampler_d
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
     p.xg32 = take((size_t)p.rows_g * D * 4);
-    p.xl32 = take(post ? (size_t)n_images * n_local * post->n_kv * D * 4 : 0);
+    p.xl32 = take(0);                 // (round 5: the local crops' fp32 copy is gone -- post_qformer's LayerNorm reads the T features)
     p.stack = take((size_t)p.rows_all * D * 2);
     p.e = take((size_t)p.rows_all * H * 4);
     p.mlp = take(mlp_plan(m, (int)p.rows_all).total);
@@ -518,7 +534,6 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
     }
     char* w = (char*)ws;
     float* xg32 = (float*)(w + p.xg32);
-    float* xl32 = (float*)(w + p.xl32);
     char* stack = w + p.stack;
     float* e = (float*)(w + p.e);
     const int period = 1 + n_local;
@@ -536,9 +551,11 @@ extern "C" int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resa
         TRY(slime_resampler_forward(attn, xg32, D, n_images, nullptr, stack + (size_t)seg_attn * D * 2, w + p.res,
                                     res_plan(attn, n_images).total, stream));
     if (post) {
-        TRY(slime_select_crops(feats, dt, P, D, period, 1, n_local, n_images, xl32, nullptr, stream));
-        TRY(slime_resampler_forward(post, xl32, D, n_images * n_local, nullptr, stack + (size_t)seg_local * D * 2, w + p.res,
-                                    res_plan(post, n_images * n_local).total, stream));
+        // local crops: post_qformer's first LayerNorm reads them straight from the tower's T features (round 5: no fp32 copy --
+        // 75 MB written and read back per 8 x (1+4) step --, no select_crops launch; float(T) either way: bit-identical)
+        const ResCrops rc{feats, period, 1, n_local, n_images};
+        TRY(resampler_run(post, nullptr, 0, &rc, n_images * n_local, nullptr, stack + (size_t)seg_local * D * 2, w + p.res,
+                          res_plan(post, n_images * n_local).total, stream));
     }
     // projection MLP over the stack.  With both experts (learnable_gated < 0) the gate mixes the HIDDEN rows of the two global
     // segments (slime_gate_premix, into the second one) and projection[2] runs over [mixed global | local] = one row per output

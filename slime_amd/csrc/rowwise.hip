@@ -15,6 +15,10 @@ struct LnArgs {
     const float* x; int ldx; int rows;
     const float* w; const float* b; float eps; int normalize;
     float* out_f32; void* out_t; void* out_t2; const float* add; int add_period;
+    // round 5 (fused adapter): the rows come straight from the tower's T features [crops, P, D] -- row r = (selected crop j = r / P, token
+    // r % P), crop j = image (j / per_image) * period + first + j % per_image, as slime_select_crops picks them -- and are widened to
+    // fp32 here (the same float(T) the separate select_crops copy produced: bit-identical), instead of being copied out as fp32 first
+    const char* xt; int P, period, first, per_image;
 };
 
 template <typename T, int VPL>
@@ -25,17 +29,34 @@ __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
-    const float* xr = a.x + (size_t)row * a.ldx;
     float v[VPL];
+    if (a.xt) {
+        const long j = row / a.P, tok = row % a.P;
+        const long crop = (j / a.per_image) * a.period + a.first + j % a.per_image;
+        const char* xr = a.xt + ((size_t)crop * a.P + tok) * D * 2;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (i * 64 + lane) * VEC;
-        if constexpr (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(xr + c);
-            v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
-        } else {
-            const float2 t = *reinterpret_cast<const float2*>(xr + c);
-            v[i * 2 + 0] = t.x; v[i * 2 + 1] = t.y;
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if constexpr (VEC == 4) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(xr + (size_t)c * 2);
+                v[i * 4 + 0] = T::lo(t[0]); v[i * 4 + 1] = T::hi(t[0]); v[i * 4 + 2] = T::lo(t[1]); v[i * 4 + 3] = T::hi(t[1]);
+            } else {
+                const unsigned t = *reinterpret_cast<const unsigned*>(xr + (size_t)c * 2);
+                v[i * 2 + 0] = T::lo(t); v[i * 2 + 1] = T::hi(t);
+            }
+        }
+    } else {
+        const float* xr = a.x + (size_t)row * a.ldx;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * VEC;
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xr + c);
+                v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+            } else {
+                const float2 t = *reinterpret_cast<const float2*>(xr + c);
+                v[i * 2 + 0] = t.x; v[i * 2 + 1] = t.y;
+            }
         }
     }
     if (a.normalize) {
@@ -106,7 +127,16 @@ extern "C" int slime_layernorm(const float* x, int ldx, int rows, int D, const f
     SLIME_REQUIRE(!normalize || (w && b), "layernorm: missing affine parameters");
     SLIME_REQUIRE(!out_t2 || (add && add_period > 0), "layernorm: out_t2 needs add/add_period");
     SLIME_REQUIRE(ldx % 4 == 0, "layernorm: ldx must be a multiple of 4");
-    LnArgs a{x, ldx, rows, w, b, eps, normalize, out_f32, out_t, out_t2, add, add_period};
+    LnArgs a{x, ldx, rows, w, b, eps, normalize, out_f32, out_t, out_t2, add, add_period, nullptr, 0, 0, 0, 0};
+    if (dtype == SLIME_F16) return launch_ln<F16>(a, D, (hipStream_t)stream);
+    return launch_ln<BF16>(a, D, (hipStream_t)stream);
+}
+
+// internal (not part of the C ABI): slime_layernorm over the rows of SELECTED crops of the tower's T features (see LnArgs.xt)
+int layernorm_crops_launch(const void* feats, int dtype, int P, int period, int first, int per_image, int images, int D, const float* w,
+                           const float* b, float eps, void* out_t, void* out_t2, const float* add, int add_period, void* stream) {
+    SLIME_REQUIRE(feats && w && b && P > 0 && per_image > 0 && images > 0 && first >= 0 && first + per_image <= period, "layernorm_crops: bad input");
+    LnArgs a{nullptr, 0, images * per_image * P, w, b, eps, 1, nullptr, out_t, out_t2, add, add_period, (const char*)feats, P, period, first, per_image};
     if (dtype == SLIME_F16) return launch_ln<F16>(a, D, (hipStream_t)stream);
     return launch_ln<BF16>(a, D, (hipStream_t)stream);
 }
