@@ -61,16 +61,16 @@ __device__ __forceinline__ void pe_cls_row(const PEArgs& a, const long grow, con
     const float mean = wave_sum(s) * (1.0f / D);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
-    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
+    for (int i = 0; i < VPL; ++i) { const float d = __fsub_rn(v[i], mean); q = __fmaf_rn(d, d, q); }
+    const float rstd = rsqrtf(__fmaf_rn(wave_sum(q), 1.0f / D, a.eps));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * VEC;
         float sx = 0.f, sq = 0.f;
 #pragma unroll
         for (int j = 0; j < VEC; j += 2) {
-            const float y0 = (v[i * VEC + j] - mean) * rstd * a.ln_w[c + j] + a.ln_b[c + j];
-            const float y1 = (v[i * VEC + j + 1] - mean) * rstd * a.ln_w[c + j + 1] + a.ln_b[c + j + 1];
+            const float y0 = __fmaf_rn(__fmul_rn(__fsub_rn(v[i * VEC + j], mean), rstd), a.ln_w[c + j], a.ln_b[c + j]);
+            const float y1 = __fmaf_rn(__fmul_rn(__fsub_rn(v[i * VEC + j + 1], mean), rstd), a.ln_w[c + j + 1], a.ln_b[c + j + 1]);
             if (a.h) { a.h[grow * D + c + j] = y0; a.h[grow * D + c + j + 1] = y1; }
             const unsigned pk = T::pack2(y0, y1);
             const float r0 = T::lo(pk), r1 = T::hi(pk);
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(NW * 64) patch_embed_kernel(PEArgs a) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const float d = acc[mi][f][k] - mean[mi]; q = fmaf(d, d, q); }
+            for (int k = 0; k < 4; ++k) { const float d = __fsub_rn(acc[mi][f][k], mean[mi]); q = __fmaf_rn(d, d, q); }
         part[mi] = pe_rows4_allsum(q);
     }
     all_waves(part);
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(NW * 64) patch_embed_kernel(PEArgs a) {
     }
 #pragma unroll
     for (int mi = 0; mi < PE_MT; ++mi) {
-        const float rstd = rsqrtf(part[mi] * (1.0f / D) + a.eps);
+        const float rstd = rsqrtf(__fmaf_rn(part[mi], 1.0f / D, a.eps));       // (operations written out: no contraction left to the compiler)
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float sx = 0.f, sq = 0.f;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(NW * 64) patch_embed_kernel(PEArgs a) {
                 const int p = 2 * t + h2;
                 float y[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (acc[mi][2 * p + (e >> 2)][e & 3] - mean[mi]) * rstd * gw[p][e] + gb[p][e];
+                for (int e = 0; e < 8; ++e) y[e] = __fmaf_rn(__fmul_rn(__fsub_rn(acc[mi][2 * p + (e >> 2)][e & 3], mean[mi]), rstd), gw[p][e], gb[p][e]);
                 const size_t off = (size_t)grow[mi] * D + cw0 + 32 * p + 8 * lg;
                 const u32x4 w = pack8<T>(y);
                 float r[8];

@@ -64,16 +64,18 @@ __global__ void __launch_bounds__(256) layernorm_kernel(LnArgs a) {
 #pragma unroll
         for (int i = 0; i < VPL; ++i) s += v[i];
         const float mean = wave_sum(s) * (1.0f / D);
+        // the operations are written out (no contraction left to the compiler): adding the T-input branch above moved the generated
+        // code of this block and with it the last bit of every output -- pinned since round 5
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
-        const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + a.eps);
+        for (int i = 0; i < VPL; ++i) { const float d = __fsub_rn(v[i], mean); q = __fmaf_rn(d, d, q); }
+        const float rstd = rsqrtf(__fmaf_rn(wave_sum(q), 1.0f / D, a.eps));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (i * 64 + lane) * VEC;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                v[i * VEC + j] = (v[i * VEC + j] - mean) * rstd * a.w[c + j] + a.b[c + j];
+                v[i * VEC + j] = __fmaf_rn(__fmul_rn(__fsub_rn(v[i * VEC + j], mean), rstd), a.w[c + j], a.b[c + j]);
         }
     }
     const float* addr = a.out_t2 ? a.add + (size_t)(row % a.add_period) * D : nullptr;
