@@ -529,3 +529,32 @@ def test_ctypes_mirrors_match_the_header_layout(tmp_path):
     assert len(epi) == 9
     for e in epi:
         assert int(got[e]) == getattr(_lib, e[len("SLIME_"):]), e
+
+
+def test_weight_residency_policy(monkeypatch):
+    """ops.pack_static (round 5): a weight whose fragment-order image exists is resident ONCE -- the row-major tensor is dropped --
+    unless SLIME_KEEP_ROW_MAJOR=1; a weight the library cannot run from its image alone keeps its row-major tensor; and
+    packed_weight_bytes counts every tensor once.  (The packing itself is a device kernel: a stand-in here.)"""
+    import torch
+    from slime_amd import ops
+    made = []
+
+    def fake_pack(w):
+        if w is None or w.shape[-2] % 64 or w.shape[-1] % 64:
+            return None
+        made.append(tuple(w.shape))
+        return w.clone()
+    monkeypatch.setattr(ops, "pack_b_frag", fake_pack)
+    monkeypatch.delenv("SLIME_KEEP_ROW_MAJOR", raising=False)
+    T = {"w_a": torch.zeros(2, 128, 64, dtype=torch.bfloat16), "w_b": torch.zeros(96, 64, dtype=torch.bfloat16), "bias": torch.zeros(128)}
+    ops.pack_static(T, ("w_a", "w_b"))
+    assert T["w_a"] is None and T["w_a_frag"] is not None            # one copy: the fragment image
+    assert T["w_b"] is not None and T["w_b_frag"] is None            # 96 rows: not packable, stays row-major
+    assert ops.packed_weight_bytes(T) == 2 * 128 * 64 * 2 + 96 * 64 * 2 + 128 * 4
+    assert ops.packed_weight_bytes(T, T) == ops.packed_weight_bytes(T)          # a tensor shared by two packs counts once
+    monkeypatch.setenv("SLIME_KEEP_ROW_MAJOR", "1")
+    T2 = {"w_a": torch.zeros(128, 64, dtype=torch.bfloat16)}
+    ops.pack_static(T2, ("w_a",))
+    assert T2["w_a"] is not None and T2["w_a_frag"] is not None and ops.keep_row_major()
+    with pytest.raises(ValueError, match="static operand"):
+        ops.gemm(torch.zeros(4, 64), None, None, 0)
