@@ -558,3 +558,63 @@ def test_weight_residency_policy(monkeypatch):
     assert T2["w_a"] is not None and T2["w_a_frag"] is not None and ops.keep_row_major()
     with pytest.raises(ValueError, match="static operand"):
         ops.gemm(torch.zeros(4, 64), None, None, 0)
+
+
+@pytest.mark.parametrize("nw,nh,merge", [(2, 2, True), (2, 3, True), (4, 4, True), (1, 2, True), (2, 2, False)])
+def test_adapter_row_map_restates_the_spatial_merge(nw, nh, merge):
+    """rowwise.hip: adapter_row_map_kernel (round 5), restated: GEMM row r of projection[2]'s output [global rows of every image | local
+    rows of every image] -> row of the [images, stride, H] token buffer.  Held against the oracle's spatial_merge (llava_arch.py:235-244)
+    and the flat order (:233-234): scattering row ids through the map must reproduce cat(global, merged local) per image."""
+    import torch
+    from oracle import slime_oracle as O
+    images, P, g = 3, 576, 12
+    n_local, q = nw * nh, g * g
+    stride = P + n_local * q + 5                                      # a wider token buffer: the extra rows stay untouched
+    rows_g, rows_l, per = images * P, images * n_local * q, n_local * q
+    dst = []
+    for r in range(rows_g + rows_l):                                  # the kernel's arithmetic
+        if r < rows_g:
+            dst.append((r // P) * stride + r % P)
+        else:
+            qq = r - rows_g
+            b, rr = qq // per, qq % per
+            d = rr
+            if merge:
+                qx, qy, k = rr % g, (rr // g) % g, rr // (g * g)
+                gx, gy = k % nw, k // nw
+                d = ((gy * g + qy) * nw + gx) * g + qx
+            dst.append(b * stride + P + d)
+    assert len(set(dst)) == len(dst)                                  # a scatter without collisions
+    buf = torch.full((images * stride, 1), -1.0)
+    buf[torch.tensor(dst)] = torch.arange(rows_g + rows_l, dtype=torch.float32)[:, None]
+    buf = buf.view(images, stride)
+    for b in range(images):
+        glob = torch.arange(b * P, (b + 1) * P, dtype=torch.float32)
+        loc = torch.arange(rows_g + b * per, rows_g + (b + 1) * per, dtype=torch.float32).view(n_local, q, 1)
+        want_loc = O.spatial_merge(loc, nw, nh, g).view(-1) if merge else loc.view(-1)
+        assert torch.equal(buf[b, :P], glob) and torch.equal(buf[b, P:P + per], want_loc) and bool((buf[b, P + per:] == -1).all())
+
+
+@pytest.mark.parametrize("dt,bits", [(torch.bfloat16, 16), (torch.float16, 21)])
+def test_split_residual_stream_keeps_the_stated_bits(dt, bits):
+    """The 2 x 16-bit split residual stream as arithmetic, on the CPU: hi = T(c), lo = T(c - hi) over the tower's 46
+    residual updates against an fp32 stream fed the same increments.  float(hi) + float(lo) and c - float(hi) are exact in fp32, so the
+    only loss is lo's rounding: <= 2^-bits of |c| per update (bf16 16 bits, fp16 21 + its subnormal floor), and the drift of the whole
+    chain stays two orders below the 2^-9 / 2^-12 operand rounding the MFMAs apply to hi anyway."""
+    g = torch.Generator().manual_seed(0)
+    h32 = torch.randn(64, 1024, generator=g) * 1.5
+    h32[:, 7] *= 60.0                                                 # an outlier channel
+    hi = h32.to(dt)
+    lo = (h32 - hi.float()).to(dt)
+    worst = 0.0
+    for step in range(46):
+        delta = torch.randn(64, 1024, generator=g) * 0.25
+        h32 = h32 + delta
+        c = delta + (hi.float() + lo.float())                         # the epilogue: acc + (bias + (float(hi) + float(lo)))
+        hi = c.to(dt)
+        assert torch.equal((c - hi.float()).double(), c.double() - hi.double())          # the difference is exact in fp32
+        lo = (c - hi.float()).to(dt)
+        err = ((hi.float() + lo.float()) - c).abs() - c.abs() * 2.0 ** -bits
+        assert float(err.max()) <= (0.0 if dt == torch.bfloat16 else 2.0 ** -24)
+        worst = max(worst, float(((hi.double() + lo.double()) - h32.double()).norm() / h32.double().norm()))
+    assert worst < (3e-5 if dt == torch.bfloat16 else 1e-6)           # end of chain vs the fp32 stream: << 2^-9 = 2e-3 / 2^-12 = 2.4e-4
