@@ -618,3 +618,40 @@ def test_split_residual_stream_keeps_the_stated_bits(dt, bits):
         assert float(err.max()) <= (0.0 if dt == torch.bfloat16 else 2.0 ** -24)
         worst = max(worst, float(((hi.double() + lo.double()) - h32.double()).norm() / h32.double().norm()))
     assert worst < (3e-5 if dt == torch.bfloat16 else 1e-6)           # end of chain vs the fp32 stream: << 2^-9 = 2e-3 / 2^-12 = 2.4e-4
+
+
+def test_fragment_staging_feeds_the_same_operands_as_row_major_staging():
+    """gemm.hip, round 5, restated on the host: the LDS-staged kernels stage a B tile either from the row-major image (LDS row rho holds
+    weight row nphys(rho), its eight 16-byte k-chunks XOR-swizzled) or by copying whole fragments of the slime_gemm_pack_b image (LDS =
+    [16-row block][k-step][lane]).  For every lane of every fragment read both forms must hand the MFMA the same weight row and the same
+    eight k -- that is why the two are bit-identical -- and frag_piece_offset must address the documented unit
+    ((t K/32 + s) 4 + f) 64 + lane of the image."""
+    import numpy as np
+    N, K = 256, 192                                                   # 4 fragment tiles of 64 rows, 6 k-steps = 3 k-tiles
+    W = (np.arange(N * K, dtype=np.int64)).reshape(N, K)              # element id = n K + k
+    KS = K // 32
+    img = np.empty((N // 64, KS, 4, 64, 8), dtype=np.int64)           # include/slime_hip.h: out[((t KS + s) 4 + f) 64 + lane] (16-byte units)
+    for t in range(N // 64):
+        for s in range(KS):
+            for f in range(4):
+                for lane in range(64):
+                    row = 64 * t + 32 * (f >> 1) + 8 * ((lane & 15) >> 2) + 4 * (f & 1) + (lane & 3)
+                    img[t, s, f, lane] = W[row, 32 * s + 8 * (lane >> 4): 32 * s + 8 * (lane >> 4) + 8]
+    flat = img.reshape(-1, 8)                                         # one row per 16-byte unit
+
+    def frag_piece_offset(blk, ks):                                   # bytes, relative to the tile's first fragment (gemm.hip)
+        return (((blk >> 2) * (K >> 5) + ks) * 4 + (blk & 3)) * 1024
+    for ktile in range(K // 64):
+        for blk in range(N // 16):                                    # 16-row MFMA block of the tile = 4 t + f
+            for ks in range(2):                                       # k-step inside the 64-wide k-tile
+                unit0 = (frag_piece_offset(blk, ks) + ktile * 8192) // 16
+                assert unit0 == (((blk >> 2) * KS + 2 * ktile + ks) * 4 + (blk & 3)) * 64
+                for lane in range(64):
+                    lq, li = lane >> 4, lane & 15
+                    got = flat[unit0 + lane]                          # whole-fragment copy: LDS[block][ks][lane] = image unit, read by lane `lane`
+                    # the row-major form: LDS row rho = 16 blk + li holds weight row nphys(rho); the lane reads chunk 4 ks + lq of the k-tile
+                    rho = 16 * blk + li
+                    nl = rho & 15
+                    nphys = (rho & ~31) + 8 * (nl >> 2) + 4 * ((rho >> 4) & 1) + (nl & 3)
+                    k0 = 64 * ktile + 32 * ks + 8 * lq
+                    assert np.array_equal(got, W[nphys, k0:k0 + 8]), (ktile, blk, ks, lane)
