@@ -2038,6 +2038,8 @@ static int auto_tile(const GemmArgs& g) {
     // throughput.  Same k order per accumulator, same epilogue: bit-identical to every other tile.
 #if SLIME_OPT_TILE64 == 2      // measured alternative: every grid of at most one 128 x 128 workgroup per CU (tools/small_latency_ab.py)
     if (tile == 15) tile = 18;
+#elif SLIME_OPT_TILE64 == 3    // measured alternative: the same, for the long-K launches only (fc2: 64 k-tiles per workgroup): slower from 4 crops on
+    if (tile == 15 && (g.K >= 2048 || (long)((g.M + 127) / 128) * (g.N / 128) * 2 <= num_cus())) tile = 18;
 #elif SLIME_OPT_TILE64
     if (tile == 15 && (long)((g.M + 127) / 128) * (g.N / 128) * 2 <= num_cus()) tile = 18;
 #endif
