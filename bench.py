@@ -56,10 +56,10 @@ GF_GLOBAL_PER_IMAGE = 35.185           # EXECUTED since round 4: the gate mixes 
                                        # token (-2 x 576 x 4096 x 4096 flop per image); rates below are priced on the executed arithmetic
 GF_LOCAL_PER_CROP = 9.399              # post_qformer + MLP per local crop
 PEAK_BF16_TFLOPS = 2500.0              # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-# What the matrix pipes deliver on THIS chip with fresh random bf16 operands in every MFMA and nothing else in the stream (the chip
-# clocks to its 1400 W cap: profiles/r04_ps_ablation.txt, profiles/r04_power_cap.txt).  Reported beside `peak`, never instead of it.
-MFMA_STREAM_AT_POWER_CAP_TFLOPS = 1616.0
-PMC_FILE = "r05_pmc_kernels.json"      # committed rocprofv3 --pmc summary the `traffic` figure is read from
+# committed rocprofv3 --pmc summary the `traffic` figure is read from: the newest round's that exists (the line names file and commit)
+PMC_FILE = next((f for f in ("r06_pmc_kernels.json", "r05_pmc_kernels.json") if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f))),
+                "r06_pmc_kernels.json")
+REPEATS = 3                            # the K-step region is timed this many times back to back; the headline is the FIRST (the driver-visible) one
 
 CONFIGS = {                            # images per step, local crops per image, local grid
     2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
@@ -105,6 +105,192 @@ def gemm_algorithmic_bytes(kid, M, N, K, split_residual=True):
     if split_residual:                                      # out_proj / fc2 on the 2 x 16-bit split residual stream (round 5): hi + lo read and written
         return b + 4 * M * N * 2 + M * (N // 64) * 8
     return b + 2 * M * N * 4 + M * N * 2 + M * (N // 64) * 8   # rounds 1-4: fp32 residual read + write, T(h), partial sums
+
+
+class BoxSampler:
+    """sclk / mclk / socket power / hot-spot temperature of this rank's GPU, sampled on a thread while the bench runs, so that a
+    slow box can be told from a regression (boxes of this pool run the same kernels 8-9 % apart).  Source, in
+    order of preference: amdsmi in-process (gpu_metrics table, ~0.1 ms per read), the amdgpu hwmon files in sysfs, `rocm-smi`
+    as a subprocess (slow: 0.5 s period).  Every sample carries the phase label that was current when it was taken; `summary()`
+    reduces them to mean / min / max per phase.  A box with no readable source yields {"source": None} -- never an exception."""
+
+    FIELDS = ("sclk_mhz", "mclk_mhz", "power_w", "temp_c")
+
+    def __init__(self, device_index=0, period=0.02):
+        import threading
+        self.period, self.phase, self.samples = period, "init", []
+        self._stop, self._thread, self.source, self.note = threading.Event(), None, None, None
+        self._read = self._open(device_index)
+        if self._read is not None:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    # -- sources ---------------------------------------------------------------------------------------------------------
+    def _open(self, idx):
+        for fn in (self._open_amdsmi, self._open_sysfs, self._open_rocm_smi):
+            try:
+                rd = fn(idx)
+                if rd is not None and any(v is not None for v in rd().values()):
+                    return rd
+            except Exception as e:                               # a missing driver / permission: try the next source
+                self.note = f"{fn.__name__}: {type(e).__name__}: {e}"[:160]
+        return None
+
+    @staticmethod
+    def _num(x):
+        if isinstance(x, (int, float)) and not isinstance(x, bool):
+            return float(x)
+        if isinstance(x, (list, tuple)):
+            v = [float(y) for y in x if isinstance(y, (int, float)) and not isinstance(y, bool) and 0 < y < 65535]
+            return sum(v) / len(v) if v else None
+        return None
+
+    def _open_amdsmi(self, idx):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        h = hs[idx if idx < len(hs) else 0]
+        try:                                                     # rank -> GPU by PCI address when torch knows it (HIP_VISIBLE_DEVICES re-orders)
+            want = torch.cuda.get_device_properties(idx).pci_bus_id
+            for c in hs:
+                bdf = amdsmi.amdsmi_get_gpu_device_bdf(c)
+                if int(bdf.split(":")[1], 16) == int(want):
+                    h = c
+        except Exception:
+            pass
+        num = self._num
+
+        def rd():
+            m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+            sclk = num(m.get("current_gfxclk"))
+            if sclk is None or not (0 < sclk < 65535):
+                sclk = num(m.get("current_gfxclks"))
+            pw = num(m.get("current_socket_power"))
+            if pw is None or not (0 < pw < 65535):
+                pw = num(m.get("average_socket_power"))
+            return {"sclk_mhz": sclk, "mclk_mhz": num(m.get("current_uclk")), "power_w": pw, "temp_c": num(m.get("temperature_hotspot"))}
+        self.source = "amdsmi gpu_metrics (in-process)"
+        return rd
+
+    def _open_sysfs(self, idx):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        if not cards:
+            return None
+        hw = cards[idx if idx < len(cards) else 0]
+
+        def f(name, scale):
+            try:
+                return float(open(os.path.join(hw, name)).read().strip()) * scale
+            except (OSError, ValueError):
+                return None
+
+        def rd():
+            pw = f("power1_input", 1e-6)
+            return {"sclk_mhz": f("freq1_input", 1e-6), "mclk_mhz": f("freq2_input", 1e-6),
+                    "power_w": pw if pw is not None else f("power1_average", 1e-6), "temp_c": f("temp2_input", 1e-3)}
+        self.source = f"sysfs {hw}"
+        return rd
+
+    def _open_rocm_smi(self, idx):
+        import re
+        import shutil
+        import subprocess
+        if not shutil.which("rocm-smi"):
+            return None
+        self.period = max(self.period, 0.5)
+
+        def rd():
+            o = subprocess.run(["rocm-smi", "-d", str(idx), "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=20).stdout
+
+            def grab(pat):
+                m = re.search(pat, o)
+                return float(m.group(1)) if m else None
+            return {"sclk_mhz": grab(r"sclk clock level: \d+: \((\d+)Mhz\)"), "mclk_mhz": grab(r"mclk clock level: \d+: \((\d+)Mhz\)"),
+                    "power_w": grab(r"Power \(W\): ([0-9.]+)"), "temp_c": grab(r"junction\) \(C\): ([0-9.]+)")}
+        self.source = "rocm-smi (subprocess, 0.5 s period)"
+        return rd
+
+    # -- sampling --------------------------------------------------------------------------------------------------------
+    def _loop(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append((self.phase, time.perf_counter(), self._read()))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def mark(self, phase):
+        self.phase = phase
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=5)
+
+    def phase_stats(self, phase):
+        rows = [v for ph, _, v in self.samples if ph == phase]
+        out = {"samples": len(rows)}
+        for k in self.FIELDS:
+            xs = [r[k] for r in rows if r.get(k) is not None]
+            if xs:
+                out[k] = {"mean": round(sum(xs) / len(xs), 1), "min": round(min(xs), 1), "max": round(max(xs), 1)}
+        return out
+
+    def summary(self, phases):
+        if self._read is None:
+            return {"source": None, "note": self.note or "no amdsmi / hwmon / rocm-smi on this box"}
+        out = {"source": self.source, "period_s": self.period, **{ph: self.phase_stats(ph) for ph in phases}}
+        t = out.get("timed", {})
+        for k in ("sclk_mhz", "power_w", "temp_c", "mclk_mhz"):      # the flat keys the VERDICT asks for
+            if k in t:
+                out[k + "_timed"] = t[k]["mean"]
+        return out
+
+
+def mfma_stream_calibration(dev, dt, box=None, seconds=0.3):
+    """THIS box's bare MFMA stream, measured in this run (slime_mfma_stream_probe: register-resident random operands, two waves per
+    SIMD, nothing but v_mfma in the loop): the rate the matrix pipes deliver under the 1400 W cap right now, with the clocks / power
+    the sampler saw meanwhile.  ~`seconds` of GPU time, HIP events on the launching stream."""
+    import ctypes as C
+    from slime_amd import ops, _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    g = torch.Generator(device="cpu").manual_seed(77)
+    operands = torch.randn(cus * 8 * 8192, generator=g).to(dt).to(dev)               # 16 KiB of fresh random values per wave
+    out = torch.empty(cus * 512, dtype=torch.float32, device=dev)
+    fl = C.c_double(0.0)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch(iters):
+        _lib.check(lib.slime_mfma_stream_probe(ops.dtype_code(dt), iters, operands.data_ptr(), operands.numel() * 2, out.data_ptr(), out.numel() * 4,
+                                               C.byref(fl), st), "mfma_stream_probe")
+    iters = 4000
+    launch(iters)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(iters); e1.record()
+    torch.cuda.synchronize()
+    ms1 = e0.elapsed_time(e1)
+    n = max(3, int(seconds * 1e3 / max(ms1, 1e-3)))
+    if box:
+        box.mark("calibration")
+    per = []
+    for _ in range(n):                                           # per-launch events: the first launches run before the chip settles at the cap
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); launch(iters); b.record()
+        per.append((a, b))
+    torch.cuda.synchronize()
+    if box:
+        box.mark("after_calibration")
+    tf = [fl.value / (a.elapsed_time(b) * 1e-3) / 1e12 for a, b in per]
+    settled = tf[len(tf) // 2:]                                  # second half: at the power cap
+    assert torch.isfinite(out).all()
+    return {"tflops": round(sum(settled) / len(settled), 1), "tflops_first_launch": round(tf[0], 1), "tflops_min": round(min(tf), 1), "tflops_max": round(max(tf), 1),
+            "launches": n, "ms_per_launch": round(ms1, 3), "gflop_per_launch": round(fl.value / 1e9, 1),
+            "what": "slime_mfma_stream_probe: bare v_mfma_f32_16x16x32_bf16 stream, register-resident random operands (16 KiB per wave), 8 waves per CU, no memory "
+                    "instruction in the loop; mean of the second half of the launches (the chip has settled at its power cap)",
+            **({"box": box.phase_stats("calibration")} if box else {})}
 
 
 def kernel_roofline(vision_model, pixels_half, reps=1):
@@ -321,21 +507,27 @@ def main():
     n_step = IMAGES * CPI                                # crops per step per GPU (config 2/4) or in total (config 3)
     strong = C["scaling"] == "strong"
     extra_cfg = {}
+    box = BoxSampler(local_rank)                         # clocks / power / temperature of this rank's GPU, sampled from here on
+    box.mark("setup")
 
     # Steps are independent batches, so the tail of step i (all-gather + adapter: small, partly under-filled launches,
     # and for N > 1 an xGMI transfer) is enqueued on its own stream and runs under the tower of step i+1; the timed
     # region ends with a device-wide synchronize, i.e. all K steps are complete inside it.
     tail_stream = None if args.no_pipeline else torch.cuda.Stream(device=dev)
+    cur = {}                                             # what the weak step runs on (re-pointed for the fp16 leg)
 
-    if not strong:
+    def weak_step_fns():
+        """Weak scaling: 40 crops per GPU, every rank owns whole images."""
         pixels = W.synthetic_pixels(n_step, seed=100 + rank).to(dev).to(dt)     # resident in HBM before timing
-        cur = {"pixels": pixels, "pg": pg, "post": post, "dt": dt, "tower": tower}   # what step() runs on (re-pointed for the fp16 leg)
+        cur.update({"pixels": pixels, "pg": pg, "post": post, "dt": dt, "tower": tower})
 
         def tail(feats):
             if collective:
                 # weak scaling: every rank owns whole images, so the adapter needs no remote features.  north_star asks for the
                 # all-gather that reassembles the visual tokens on every rank (the LLM consumes all of them); it is issued
-                # asynchronously and overlaps the adapter, which works on the rank's own block.
+                # asynchronously and overlaps the adapter, which works on the rank's own block.  Nothing on this path READS the
+                # gathered tensor (`gather_consumed: false` in the line): the data flow north_star describes -- gather BEFORE the
+                # adapter -- is the strong form, timed in the same run as the `strong` object.
                 allf = torch.empty((world * feats.shape[0],) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
                 work = dist.all_gather_into_tensor(allf, feats.contiguous(), async_op=True)
             out = ops.adapter_forward(cur["pg"], cur["post"], feats, IMAGES, LOCAL, NW, NH, True, -1, cur["dt"])
@@ -345,19 +537,24 @@ def main():
 
         def produce():
             return cur["tower"](cur["pixels"])                                   # [40,576,1024] bf16
-        extra_cfg["gather"] = "async all-gather of the rank's bf16 tower features, overlapping the adapter (overhead-only in weak scaling: each rank's adapter reads its own block)" if collective else "none"
-    else:
-        # strong scaling (config 3): identical crop list on every rank; rank r encodes its block, the exchange reassembles
-        # what the adapter needs, the adapter runs for the images this rank owns
+        cfg = {"gather": "async all-gather of the rank's bf16 tower features, overlapping the adapter (overhead-only in weak scaling: each rank's adapter "
+                         "reads its own block)" if collective else "none"}
+        if collective:
+            cfg["gather_consumed"] = False
+        return pixels, produce, tail, cfg
+
+    def strong_step_fns(gather_mode):
+        """Strong scaling (config 3 / 5, config 2 with --scaling strong, and the `strong` object of the default N > 1 line): the
+        identical crop list on every rank; rank r encodes its block, the exchange reassembles what the adapter needs BEFORE the
+        adapter (north_star / SURVEY 8e), the adapter runs for the images this rank owns."""
         pixels = W.synthetic_pixels(n_step, seed=100).to(dev).to(dt)
         vm = tower.vision_tower
         # config 5: every rank needs every frame's tokens for the (replicated) prefill, so the adapter runs for all of them
         my_images = list(range(IMAGES)) if args.config == 5 else D.image_shard(IMAGES, world, rank)
         lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
-
         per_rank_crops = -(-n_step // world)
         chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world, device_name=torch.cuda.get_device_name(dev),
-                                                      model="CLIP-ViT-L/14-336", dtype="bf16")}.get(args.gather, 0)
+                                                      model="CLIP-ViT-L/14-336", dtype="bf16")}.get(gather_mode, 0)
 
         def tower_fn(x):
             return vm.encode(x, -2, False, dt)
@@ -366,21 +563,25 @@ def main():
             return ops.resampler_forward(post, x.float(), want_t=True)[1]
 
         def produce():
-            if args.gather == "compressed":
+            if gather_mode == "compressed":
                 return D.sharded_tower_compressed(tower_fn, compress_fn, pixels, CPI, (576, 1024), g * g, dt)
             return D.sharded_tower(tower_fn, pixels, (576, 1024), dt, chunk=chunk)
 
         def tail(feats):
             if hi_i == lo_i:
                 return None
-            if args.gather == "compressed":
+            if gather_mode == "compressed":
                 glob, comp = feats
                 return ops.adapter_forward_precompressed(pg, glob[lo_i:hi_i], comp[lo_i * LOCAL:hi_i * LOCAL], hi_i - lo_i, LOCAL,
                                                          NW, NH, True, -1, dt)
             return ops.adapter_forward(pg, post, feats[lo_i * CPI:hi_i * CPI], hi_i - lo_i, LOCAL, NW, NH, True, -1, dt)
         full_b, comp_b = D.gather_bytes(n_step, CPI, world)
-        extra_cfg.update({"gather": args.gather, "gather_chunk": chunk, "gather_bytes_per_rank": comp_b if args.gather == "compressed" else full_b,
-                          "crops_per_rank_padded": -(-n_step // world), "images_owned_by_rank0": len(my_images)})
+        cfg = {"gather": gather_mode, "gather_chunk": chunk, "gather_bytes_per_rank": comp_b if gather_mode == "compressed" else full_b,
+               "crops_per_rank_padded": -(-n_step // world), "images_owned_by_rank0": len(my_images), "gather_consumed": True}
+        return pixels, produce, tail, cfg
+
+    pixels, produce, tail, step_cfg = strong_step_fns(args.gather) if strong else weak_step_fns()
+    extra_cfg.update(step_cfg)
 
     # config 4: splice + 32 Llama-3-8B attention sub-layers over the spliced sequences
     prefill = None
@@ -391,60 +592,102 @@ def main():
                                 shard=(world, rank) if (args.prefill_shard == "heads" and collective and world > 1) else None)
         extra_cfg["prefill_shard"] = args.prefill_shard if world > 1 else "n/a (one GPU)"
 
-    def step():
-        feats = produce()
-        if tail_stream is None:
-            out = tail(feats)
-            return prefill(out) if prefill else out
-        ready = torch.cuda.Event()
-        ready.record()
-        with torch.cuda.stream(tail_stream):
-            tail_stream.wait_event(ready)
-            for t in (feats if isinstance(feats, tuple) else (feats,)):
-                t.record_stream(tail_stream)
-            out = tail(feats)
-            return prefill(out) if prefill else out
+    def make_step(produce_fn, tail_fn, with_prefill=True):
+        def step():
+            feats = produce_fn()
+            if tail_stream is None:
+                out = tail_fn(feats)
+                return prefill(out) if (prefill and with_prefill) else out
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(tail_stream):
+                tail_stream.wait_event(ready)
+                for t in (feats if isinstance(feats, tuple) else (feats,)):
+                    t.record_stream(tail_stream)
+                out = tail_fn(feats)
+                return prefill(out) if (prefill and with_prefill) else out
+        return step
+
+    step = make_step(produce, tail)
 
     def barrier():
         if collective:
             dist.barrier()
 
-    def timed_region():
+    def timed_region(step_fn=None, warmup=None, phase="timed"):
         """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides."""
+        step_fn = step_fn or step
         out = None
-        for _ in range(args.warmup):
-            out = step()
+        box.mark("warmup")
+        for _ in range(args.warmup if warmup is None else warmup):
+            out = step_fn()
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
+        box.mark(phase)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step()
+            out = step_fn()
         torch.cuda.synchronize()
         barrier()
         dt_s = time.perf_counter() - t0
+        box.mark("between")
         if out is not None:
             assert torch.isfinite(out.float()).all()
         return dt_s
 
-    elapsed = timed_region()
-    rank_ms = [elapsed / args.steps * 1e3]
-    if collective:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    def max_over_ranks(sec):
+        """(max over ranks, every rank's own figure) of a region's wall time."""
+        if not collective:
+            return sec, [sec]
+        t = torch.tensor([sec], device=dev, dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(every, t)                            # each rank's own clock around the same K steps
-        rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return max(float(e.item()) for e in every), [float(e.item()) for e in every]
+
+    box.mark("idle")
+    time.sleep(0.15)                                         # a few samples of the idle chip (context up, weights resident, nothing running)
+    elapsed, every = max_over_ranks(timed_region())          # THE headline: warm-up, then the first K steps
+    rank_ms = [e / args.steps * 1e3 for e in every]
+    # the same K steps twice more, back to back, no warm-up (the chip is warm): run-to-run spread inside one process on one box
+    repeats_s = [elapsed] + [max_over_ranks(timed_region(warmup=0, phase="repeat"))[0] for _ in range(REPEATS - 1)]
+    box_ranks = None
+    if collective:
+        # every rank's clocks / power inside the headline region (a rank on a throttled GPU is the one the MAX over ranks reports)
+        mine = box.phase_stats("timed")
+        t = torch.tensor([mine.get(k, {}).get("mean", float("nan")) for k in ("sclk_mhz", "power_w", "temp_c")], device=dev, dtype=torch.float64)
+        allb = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allb, t)
+        box_ranks = [{k: (None if v != v else round(v, 1)) for k, v in zip(("sclk_mhz", "power_w", "temp_c"), x.tolist())} for x in allb]
         # what the communicator itself says (not the environment): backend name and the number of ranks in it
         extra_cfg["collective_backend"] = dist.get_backend()
         extra_cfg["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else None
         extra_cfg["launched_by"] = "bench.py self-launch" if os.environ.get("SLIME_BENCH_SELF_LAUNCHED") == "1" else "torch.distributed.run"
 
+    # The default N > 1 line is weak scaling (40 crops per GPU).  north_star's data flow -- the batch's crops sharded over the GPUs,
+    # an RCCL all-gather reassembling the features BEFORE the adapter -- is the strong form: timed here, in the same process group and
+    # the same run, on the same 40 crops for every N, so that one driver command returns both curves (VERDICT r5 item 3).
+    strong_obj = None
+    if collective and args.config == 2 and not strong:
+        s_pixels, s_produce, s_tail, s_cfg = strong_step_fns(args.gather)
+        s_elapsed, s_every = max_over_ranks(timed_region(make_step(s_produce, s_tail), phase="strong"))
+        pred_n, pred_1 = D.predicted_step_ms(n_step, CPI, world), D.predicted_step_ms(n_step, CPI, 1)
+        strong_obj = {"what": "the SAME 8 x (1+4) = 40 crops block-partitioned over the ranks (slime_amd.dist.sharded_tower), all-gather of the bf16 tower "
+                              "features BEFORE the adapter, adapter on the image-owning rank; same process group, same run, W warm-up + K timed steps, max over ranks",
+                      "scaling": "strong", "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "value": round(n_step * args.steps / s_elapsed, 1),
+                      "unit": "crops/s (whole job)", "ms_per_step_rank_min": round(min(s_every) / args.steps * 1e3, 3),
+                      "ms_per_step_rank_max": round(max(s_every) / args.steps * 1e3, 3),
+                      "predicted_ms_per_step": round(pred_n, 2), "predicted_ms_per_step_n1": round(pred_1, 2),
+                      "speedup_vs_n1_predicted": round(pred_1 / pred_n, 2),
+                      "prediction": "slime_amd.dist.predicted_step_ms: tower latency profile at ceil(40 / N) crops + all-gather transfer model + adapter for the rank's images (DESIGN section 7)",
+                      **s_cfg}
+        del s_pixels
+
     if rank == 0:
         crops_total = n_step * (1 if strong else world) * args.steps
         value = crops_total / elapsed
         ms_per_step = elapsed / args.steps * 1e3
+        box.mark("probe")
         step_gf = n_step * GF_VIT_PER_CROP + IMAGES * GF_GLOBAL_PER_IMAGE + IMAGES * LOCAL * GF_LOCAL_PER_CROP
         if prefill:
             step_gf += prefill.gflop
@@ -460,6 +703,7 @@ def main():
             per.update(pk)
             roof_kernel = pk["prefill_attention"]
         # the driver's line (config 2, 40 crops per GPU) must carry a traffic figure; other launch shapes carry one if profiled
+        calib = mfma_stream_calibration(dev, dt, box)
         traffic, traffic_src, traffic_head, traffic_err = pmc_traffic(roof_kernel["rocprof_name"], profiled_shape=(args.config == 2 and not strong and world == 1))
         workload = {2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
                     3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
@@ -469,6 +713,7 @@ def main():
             "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid" if args.config != 3 else "image-crops/sec (ViT+projector) at 336px, 1+16 grid",
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
+            "ms_per_step_repeats": [round(r / args.steps * 1e3, 3) for r in repeats_s],
             "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": args.config,
@@ -486,10 +731,10 @@ def main():
                           "gflop_per_step_reference_arithmetic": round(step_gf_reference, 1),
                           "gflop_note": "rates are priced on the EXECUTED arithmetic: the gated block's second Linear runs once per global token after the gate "
                                         "mixed the hidden rows (linear map, gates sum to 1/(1+1e-6)); the reference's two complete experts would be the larger figure",
-                          "power_capped_mfma_stream_tflops": MFMA_STREAM_AT_POWER_CAP_TFLOPS,
-                          "frac_of_power_capped_mfma_stream": round(path_tflops / (MFMA_STREAM_AT_POWER_CAP_TFLOPS * world), 4),
-                          "power_note": "the step runs at the 1400 W cap (sclk 1.96 of 2.40 GHz; 13.0 instead of 15.0 ms on all-zero operands): "
-                                        "profiles/r04_power_cap.txt; the bare MFMA stream on fresh random operands reaches 1616 TF/s here: profiles/r04_ps_ablation.txt"},
+                          # THIS box's bare MFMA stream, measured in this run right after the timed regions (no constant from another box)
+                          "power_capped_mfma_stream_tflops": calib["tflops"],
+                          "frac_of_power_capped_mfma_stream": round(path_tflops / (calib["tflops"] * world), 4),
+                          "mfma_stream_calibration": calib},
             "roofline": {"bound": "mfma",
                          "kernel": f"{roof_kernel['rocprof_name']} ({roof_kernel['label']}, M={roof_kernel['M']} N={roof_kernel['N']} K={roof_kernel['K']})",
                          "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -508,6 +753,8 @@ def main():
         }
         if prefill:
             res["config"].update(prefill.describe())
+        if strong_obj is not None:
+            res["strong"] = strong_obj
         if world == 1 and args.config == 2 and not strong:
             # The SAME step in the reference's inference dtype (fp16: llava/model/builder.py:43) -- the dtype whose projector
             # outputs meet north_star's 1e-3 (parity.fp16 below): same region, same K / W, timed right after the bf16 line.
@@ -520,7 +767,7 @@ def main():
             tower16, model16 = enc16.get_vision_tower(), enc16.get_model()
             cur.update(pixels=pixels.to(f16), pg=model16.mm_projector.packed(f16), post=model16.sampler.post_qformer.packed(576, f16), dt=f16,
                        tower=tower16)
-            e16 = timed_region()
+            e16 = timed_region(phase="fp16")
             res["fp16"] = {"ms_per_step": round(e16 / args.steps * 1e3, 3), "value": round(n_step * args.steps / e16, 1), "unit": "crops/s",
                            "vs_bf16": round(elapsed / e16, 4),
                            "note": "same step, same timed region, fp16 MFMA operands (the reference's inference dtype; meets the 1e-3 target, see parity.fp16)"}
@@ -529,6 +776,14 @@ def main():
         if world == 1 and args.config == 2 and not args.no_cpu_baseline:
             res["cpu_baseline"], px_s, ref_s = cpu_baseline(tower_sd, adapter_sd, CPI)
             res["parity"] = parity_vs_oracle(tower_sd, adapter_sd, px_s, ref_s, dev, NW, NH)
+        box.mark("after")
+        time.sleep(0.1)
+        box.stop()
+        res["box"] = {"device": torch.cuda.get_device_name(dev), "cus": torch.cuda.get_device_properties(dev).multi_processor_count,
+                      **box.summary(("idle", "warmup", "timed", "repeat", "strong", "probe", "calibration", "fp16", "after")),
+                      **({"ranks_timed": box_ranks} if box_ranks else {}),
+                      "what": "this rank's GPU while the bench ran: idle = context up, nothing running; timed = the headline K steps; repeat = the two repeats; "
+                              "probe = per-kernel HIP-event probing; calibration = the bare MFMA stream; after = the last 0.1 s"}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(res), flush=True)

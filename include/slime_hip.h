@@ -16,8 +16,11 @@
  *     functions declared here; the process-global tuning / ablation hooks used by tools/ live in a separate
  *     diagnostic build, libslime_hip_diag.so, compiled from the same sources with -DSLIME_DIAG); calls on
  *     distinct streams with distinct workspaces may run concurrently;
- *   - "T" is the 16-bit MFMA operand type selected by `dtype` (SLIME_BF16 or SLIME_F16); all
- *     accumulation, residual stream, LayerNorm and softmax statistics are fp32.
+ *   - "T" is the 16-bit MFMA operand type selected by `dtype` (SLIME_BF16 or SLIME_F16); accumulation and the
+ *     LayerNorm / softmax statistics are fp32; the tower's residual stream is a 2 x 16-bit SPLIT since ABI 5
+ *     (hi = T(h), lo = T(h - hi): 16 significant bits in bf16, 22 in fp16 -- SLIME_EPI_BIAS_RESID_SPLIT_LN), the
+ *     Llama decoder layer's is 16-bit as in HF (SLIME_EPI_BIAS_RESID_T); primitive-level fp32 forms remain
+ *     (SLIME_EPI_BIAS_RESID_F32[_LN]).
  */
 #ifndef SLIME_HIP_H
 #define SLIME_HIP_H
@@ -29,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 5
+#define SLIME_ABI_VERSION 6
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 
@@ -51,7 +54,11 @@ enum {
     SLIME_EPI_BIAS_RESID_T,      /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
     SLIME_EPI_BIAS_GELU_MIX_T,   /* C[t] = T(g0[t] gelu(A[t] B^T + bias) + g1[t] gelu(A2[t] B^T + bias)): GatedBlock hidden rows, mixed in fp32 (slime_gemm_ex) */
     SLIME_EPI_BIAS_RESID_SPLIT_LN /* the residual update of BIAS_RESID_F32_LN on a 2 x 16-bit SPLIT residual stream (ABI 5, slime_gemm_ex):
-                                   * h = float(C) + float(lo16); c = A*B^T + bias + h; C = T(c), lo16 = T(c - float(C)); stats_out as _LN.
+                                   * h = float(C) + float(lo16) (one fp32 addition: exact up to fp32 rounding -- lo can sit more than 24 bits
+                                   * below hi); c = A*B^T + bias + h; C = T(c), lo16 = T(c - float(C)) (that difference is exact);
+                                   * stats_out = partial sums of the UNROUNDED c, as _LN (slime_patch_embed_prenorm, the producer of layer 0's
+                                   * table, sums the ROUNDED rows T(h): the two definitions differ by ~2^-9 relative per element with random
+                                   * sign -- noise far below what a LayerNorm statistic resolves, stated here because both feed the same fold).
                                    * C is at once the upper half of the stream and the next GEMM's operand (no separate x16 copy). */
 };
 
@@ -138,7 +145,9 @@ int slime_layernorm(const float* x, int ldx, int rows, int D, const float* w, co
  *   x16   T   [n*(1+P), D]      T(h) -- the first GEMM's operand and the upper half of the split residual stream;
  *   lo16  T   [n*(1+P), D]      T(h - float(x16)), the lower half (SLIME_EPI_BIAS_RESID_SPLIT_LN);
  *   stats f32 [n*(1+P), D/64, 2] (sum, sum of squares) of the ROUNDED rows per 64-column group (first folded LayerNorm).
- * D in {128, 256, 1024}; image / patch <= 24 patches per side. */
+ * Limits (checked here, by slime_vit_check at pack time and by every slime_vit_forward*): D in {128, 256, 1024};
+ * image % patch == 0 and image % 8 == 0; image / patch <= 24 patches per side; 6 * patch * image < 65535; 16-bit pixels
+ * must already be of type T (fp32 pixels are rounded on the way in).  CLIP-L/14-336 and -224 fit; a 448 / 14 tower does not. */
 int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, const void* patch_w_frag, const float* cls, const float* pos,
                               const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo16, float* stats,
                               int dtype, int n, int image, int patch, int kpad, int D, void* stream);
@@ -296,6 +305,10 @@ typedef struct {
 } slime_vit_desc;
 
 size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
+/* Validate a descriptor without running it (host-only): the checks every slime_vit_forward* starts with -- dtype, widths,
+ * head_dim 64, the fused front end's geometry limits (slime_patch_embed_prenorm), presence of every weight.  Callers run it
+ * when they PACK a tower, so an unsupported geometry fails there with slime_last_error() naming the limit. */
+int slime_vit_check(const slime_vit_desc* d);
 /* The epilogue (SLIME_EPI_*) of the tower's out_proj / fc2 launches in this build: SLIME_EPI_BIAS_RESID_SPLIT_LN (2 x 16-bit split
  * residual stream, ABI 5) -- what a profiler label for those kernels has to be generated with (slime_gemm_kernel_name).  Host-only. */
 int slime_vit_residual_epilogue(void);
@@ -378,7 +391,10 @@ int slime_gated_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* a
  * one GEMM pair over the stacked rows; per-row results are identical to the separate calls.
  *   feats: T [n_images*(1+n_local), 576, D] tower output, crop 0 of each image = global view.
  *   out:   out_dtype [n_images, out_image_stride rows, H]; image i gets rows [0,576) = gated global tokens and
- *          rows [576, 576 + n_local*g*g) = merged local tokens (raster order if merge != 0; nw*nh == n_local). */
+ *          rows [576, 576 + n_local*g*g) = merged local tokens (raster order if merge != 0; nw*nh == n_local).
+ * projection[2] stores every row straight into `out` (slime_gemm_args.row_map) when out_dtype is fp32 or the operand type T;
+ * a 16-bit out_dtype OTHER than T (bf16 tokens from an fp16 adapter or vice versa) takes fp32 rows + slime_merge_rows_batched
+ * instead: same values, two more passes over the token rows. */
 size_t slime_adapter_workspace_bytes(const slime_mlp_desc* mlp, const slime_resampler_desc* attn,
                                      const slime_resampler_desc* post, int n_images, int n_local);
 int slime_adapter_forward(const slime_mlp_desc* mlp, const slime_resampler_desc* attn, const float* w_gate,
@@ -439,6 +455,19 @@ int slime_llama_attn_forward(const slime_llama_attn_desc* d, const void* hidden,
 int slime_llama_attn_forward_resid(const slime_llama_attn_desc* d, const void* hidden, const int32_t* position_ids,
                                    const int32_t* kv_start, const int32_t* kv_len, int batch, int S, const void* resid,
                                    void* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py; no reference counterpart)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One launch of a bare v_mfma_f32_16x16x32_{bf16,f16} stream on register-resident operands: one workgroup of 8 waves per CU,
+ * every wave multiplies the fragments of a 64 x 64 tile (2 k-steps, 32 MFMAs per iteration, 16 independent accumulators) `iters`
+ * times with no memory instruction in the loop.  operands: >= 16 KiB of finite random 16-bit values (wave w reads the 16 KiB
+ * slot w mod (operand_bytes / 16 KiB)); out: >= CUs x 512 floats (the sums, so that the loop is live); *flops_host receives the
+ * FLOPs one launch performs.  Timed by the caller with HIP events, it is THIS chip's MFMA ceiling under its power cap at this
+ * moment -- the denominator bench.py reports beside the 2.5 PFLOP/s dense peak. */
+int slime_mfma_stream_probe(int dtype, int iters, const void* operands, size_t operand_bytes, float* out, size_t out_bytes,
+                            double* flops_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BF16, F16, F32, U8 = 0, 1, 2, 3
 (EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T,
  EPI_BIAS_GELU_MIX_T, EPI_BIAS_RESID_SPLIT_LN) = range(9)
@@ -118,6 +118,8 @@ _SIGNATURES = {
     "slime_router_select_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "slime_vit_workspace_bytes": (c_size_t, [_P(VitDesc), c_int]),
     "slime_vit_residual_epilogue": (c_int, []),
+    "slime_vit_check": (c_int, [_P(VitDesc)]),
+    "slime_mfma_stream_probe": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, _P(C.c_double), c_void_p]),
     "slime_vit_forward": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                   c_size_t, c_void_p]),
     "slime_vit_forward_ex": (c_int, [_P(VitDesc), c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,

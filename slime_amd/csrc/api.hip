@@ -93,6 +93,8 @@ static VitPlan vit_plan(const slime_vit_desc* d, int n) {
     return p;
 }
 
+int slime_patch_embed_geometry(int image, int patch, int kpad, int D, size_t* lds_out);   // patch_embed.hip: the fused front end's limits
+
 static int vit_validate(const slime_vit_desc* d) {
     SLIME_REQUIRE(d, "vit: null descriptor");
     SLIME_REQUIRE(is16(d->dtype), "vit: dtype must be BF16 or F16");
@@ -100,8 +102,8 @@ static int vit_validate(const slime_vit_desc* d) {
     SLIME_REQUIRE(d->hidden % 64 == 0, "vit: hidden must be a multiple of 64 (LayerNorm partial sums per 64 columns)");
     SLIME_REQUIRE(d->heads > 0 && d->hidden % d->heads == 0 && d->hidden / d->heads == 64, "vit: head_dim must be 64");
     SLIME_REQUIRE(d->inter % 128 == 0 && d->inter % 64 == 0, "vit: intermediate size %d must be a multiple of 128", d->inter);
-    SLIME_REQUIRE(d->image % d->patch == 0, "vit: image %d not a multiple of patch %d", d->image, d->patch);
-    SLIME_REQUIRE(d->kpad % 64 == 0 && d->kpad >= 3 * d->patch * d->patch, "vit: kpad=%d", d->kpad);
+    SLIME_REQUIRE(d->patch > 0 && d->image % d->patch == 0, "vit: image %d not a multiple of patch %d", d->image, d->patch);
+    TRY(slime_patch_embed_geometry(d->image, d->patch, d->kpad, d->hidden, nullptr));      // the one-launch front end's geometry limits
     SLIME_REQUIRE(d->layers_run >= 0, "vit: layers_run < 0");
     SLIME_REQUIRE(d->patch_w_frag && d->cls && d->pos && d->pre_ln_w && d->pre_ln_b,
                   "vit: missing embedding weights (patch_w_frag = slime_gemm_pack_b of the conv weight is required since ABI 5)");
@@ -111,6 +113,8 @@ static int vit_validate(const slime_vit_desc* d) {
                   "vit: missing layer weights");
     return SLIME_OK;
 }
+
+extern "C" int slime_vit_check(const slime_vit_desc* d) { return vit_validate(d); }
 
 extern "C" int slime_vit_residual_epilogue(void) {
     return SLIME_OPT_SPLIT_RESID ? SLIME_EPI_BIAS_RESID_SPLIT_LN : SLIME_EPI_BIAS_RESID_F32_LN;

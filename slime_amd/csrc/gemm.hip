@@ -256,9 +256,10 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
             }
         }
     } else if constexpr (EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN) {
-        // The residual update on a 2 x 16-bit SPLIT stream (round 5): h = float(hi) + float(lo) (exact in fp32: the two halves do not
-        // overlap), c = acc + (bias + h), hi' = T(c), lo' = T(c - float(hi')) (the difference is exact), partial sums of c as in
-        // BIAS_RESID_F32_LN.  hi' IS the next GEMM's operand: 8 bytes per element cross the fabric here (2 + 2 in, 2 + 2 out)
+        // The residual update on a 2 x 16-bit SPLIT stream (round 5): h = float(hi) + float(lo) (one fp32 addition: exact up to fp32
+        // rounding -- lo's exponent can sit more than 24 bits below hi's), c = acc + (bias + h), hi' = T(c), lo' = T(c - float(hi'))
+        // (that difference is exact), partial sums of the UNROUNDED c as in BIAS_RESID_F32_LN (the front end, producer of layer 0's
+        // table, sums the rounded rows: include/slime_hip.h states the difference).  hi' IS the next GEMM's operand: 8 bytes per element cross the fabric here (2 + 2 in, 2 + 2 out)
         // instead of 10 (4 in, 4 + 2 out); what is kept of c are 16 (bf16) / 22 (fp16) significant bits instead of 24.
         // C (= hi) and lo are read and written in place and vmcnt counts stores: both planes are fetched one 16-row step ahead
         // (one step, not two as the fp32 epilogue: two planes' addresses + unpacked halves must fit the direct-B kernel's 128 VGPRs).

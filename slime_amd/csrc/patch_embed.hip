@@ -340,6 +340,27 @@ int launch_pe_d(const PEArgs& a, int D, size_t lds, hipStream_t s) {
 
 }  // namespace
 
+// Geometry limits of the fused front end, shared with vit_validate / slime_vit_check (api.hip) so that a tower the front end cannot
+// run is refused when it is PACKED, with the limit named, not at its first forward: two rows of at most PE_ROWS / 2 patches per
+// workgroup, whole image rows of 16-byte pieces, a 16-bit LDS offset table over the 2 x 3 x patch staged image rows, <= 160 KiB of LDS.
+int slime_patch_embed_geometry(int image, int patch, int kpad, int D, size_t* lds_out) {
+    SLIME_REQUIRE(patch > 0 && image > 0 && image % patch == 0 && image % 8 == 0,
+                  "patch_embed: image %d must be a multiple of the patch %d and of 8 (16-byte pixel pieces)", image, patch);
+    SLIME_REQUIRE(kpad % 64 == 0 && kpad >= 3 * patch * patch, "patch_embed: kpad=%d (3 * patch^2 rounded up to a multiple of 64)", kpad);
+    SLIME_REQUIRE(D == 128 || D == 256 || D == 1024, "patch_embed: D=%d unsupported (128, 256, 1024)", D);
+    const int g = image / patch;
+    SLIME_REQUIRE(2 * g <= PE_ROWS, "patch_embed: %d patches per side -- the front end holds two rows of at most %d patches per workgroup "
+                  "(CLIP-L/14-336: 24; a 448 / 14 tower would need 32)", g, PE_ROWS / 2);
+    SLIME_REQUIRE((size_t)6 * patch * image < 65535, "patch_embed: 6 * patch * image = %zu elements of staged image rows exceed the 16-bit offset table",
+                  (size_t)6 * patch * image);
+    const int nw = D == 128 ? 2 : D == 256 ? 4 : 8;
+    const size_t lds = pe_align16((size_t)6 * patch * image * 2) + (size_t)PE_ROWS * (kpad + 8) * 2 + pe_align16((size_t)kpad * 2) +
+                       (size_t)nw * PE_ROWS * sizeof(float);
+    SLIME_REQUIRE(lds <= 160 * 1024, "patch_embed: %zu bytes of LDS needed (160 KiB per CU)", lds);
+    if (lds_out) *lds_out = lds;
+    return SLIME_OK;
+}
+
 extern "C" int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, const void* patch_w_frag, const float* cls, const float* pos,
                                          const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo16, float* stats,
                                          int dtype, int n, int image, int patch, int kpad, int D, void* stream) {
@@ -349,19 +370,13 @@ extern "C" int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, cons
     SLIME_REQUIRE(!stats || x16, "patch_embed: stats are the partial sums of x16");
     SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "patch_embed: dtype must be BF16 or F16");
     SLIME_REQUIRE(pix_dtype == SLIME_F32 || pix_dtype == dtype, "patch_embed: 16-bit pixels must already be in the tower dtype");
-    SLIME_REQUIRE(patch > 0 && image % patch == 0 && image % 8 == 0, "patch_embed: image %d / patch %d", image, patch);
-    SLIME_REQUIRE(kpad % 64 == 0 && kpad >= 3 * patch * patch, "patch_embed: kpad=%d", kpad);
+    size_t lds = 0;
+    if (const int rc = slime_patch_embed_geometry(image, patch, kpad, D, &lds)) return rc;
     const int g = image / patch;
-    SLIME_REQUIRE(2 * g <= PE_ROWS, "patch_embed: %d patches per side (a workgroup holds two rows of at most %d)", g, PE_ROWS / 2);
-    SLIME_REQUIRE((size_t)6 * patch * image < 65535, "patch_embed: pixel tile too large for the 16-bit offset table");
     SLIME_REQUIRE(((uintptr_t)pixels % 16) == 0 && ((uintptr_t)patch_w_frag % 16) == 0 && ((uintptr_t)pos % 16) == 0 &&
                   ((uintptr_t)ln_w % 16) == 0 && ((uintptr_t)ln_b % 16) == 0 && (!h || (uintptr_t)h % 16 == 0) &&
                   (!x16 || (uintptr_t)x16 % 16 == 0) && (!lo16 || (uintptr_t)lo16 % 16 == 0) && (!stats || (uintptr_t)stats % 8 == 0),
                   "patch_embed: pointers must be 16-byte aligned");
-    const int nw = D == 128 ? 2 : D == 256 ? 4 : 8;
-    const size_t lds = pe_align16((size_t)6 * patch * image * 2) + (size_t)PE_ROWS * (kpad + 8) * 2 + pe_align16((size_t)kpad * 2) +
-                       (size_t)nw * PE_ROWS * sizeof(float);
-    SLIME_REQUIRE(lds <= 160 * 1024, "patch_embed: %zu bytes of LDS needed", lds);
     PEArgs a{pixels, (const char*)patch_w_frag, cls, pos, ln_w, ln_b, eps, h, (char*)x16, (char*)lo16, stats, n, image, patch, kpad, g};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SLIME_F16)

@@ -133,6 +133,31 @@ def gather_ms(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, l
     return 0.03 + (world - 1) * per_rank * bytes_per_crop / (link_gb_s * 1e6)
 
 
+# fused adapter (GatedBlock + post_qformer + MLP + merge) for k images of 1 + 4 crops on one GPU, ms (profiles/r05_adapter_direct_store.txt
+# and the per-rank rehearsals): the GatedBlock's 576-query Resampler and the stacked MLP are under-filled launches below 4 images
+ADAPTER_MS = {0: 0.0, 1: 0.3, 2: 0.4, 4: 0.6, 8: 0.7}
+
+
+def adapter_ms(images: int) -> float:
+    ks = sorted(ADAPTER_MS)
+    if images >= ks[-1]:
+        return ADAPTER_MS[ks[-1]] * images / ks[-1]
+    for a, b in zip(ks, ks[1:]):
+        if a <= images <= b:
+            return ADAPTER_MS[a] + (ADAPTER_MS[b] - ADAPTER_MS[a]) * (images - a) / (b - a)
+    return 0.0
+
+
+def predicted_step_ms(n_crops: int, crops_per_image: int, world: int, profile: Optional[dict] = None) -> float:
+    """Modelled wall time of one STRONG-scaling step (DESIGN.md section 7's table, as a function): the tower over the rank's
+    block of ceil(n_crops / world) crops (measured latency curve) + the all-gather of the tower features (transfer model above)
+    + the adapter for the images the busiest rank owns.  Nothing is assumed to overlap: an upper bound on the step, hence a lower
+    bound on the speed-up -- the figure bench.py prints beside the measured `strong` object, to be held against it."""
+    per = -(-n_crops // world)
+    images = n_crops // crops_per_image
+    return tower_ms(per, profile) + gather_ms(per, world) + adapter_ms(-(-images // world))
+
+
 def choose_chunk(per_rank: int, world: int, bytes_per_crop: int = 576 * 1024 * 2, link_gb_s: float = 100.0,
                  profile: Optional[dict] = None, device_name: Optional[str] = None, model: Optional[str] = None,
                  dtype: Optional[str] = None) -> int:

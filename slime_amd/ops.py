@@ -331,6 +331,9 @@ def pack_tower(state_dict: Dict[str, torch.Tensor], cfg: VisionConfig, dtype: to
     for name in ("patch_w", "cls", "pos", "pre_ln_w", "pre_ln_b", "w_qkv", "b_qkv", "colsum_qkv", "w_o", "b_o",
                  "w_fc1", "b_fc1", "colsum_fc1", "w_fc2", "b_fc2", "w_qkv_frag", "w_o_frag", "w_fc1_frag", "w_fc2_frag", "patch_w_frag"):
         setattr(d, name, T[name].data_ptr() if name in T and T[name] is not None else None)
+    # the driver's own validation, at PACK time: a geometry the fused front end cannot run (more than 24 patches per side, image
+    # not a multiple of 8, ...) is refused here with the limit named, not by the first forward
+    _lib.check(_lib.load().slime_vit_check(C.byref(d)), "pack_tower")
     return PackedTower(cfg, dtype, L, T, d)
 
 
@@ -843,11 +846,13 @@ class PackedLlamaAttention:
 
 
 # One grow-only Workspace per (device, stream) for the Llama attention sub-layer: ~200 MB at SliME-8B prefill shapes (8 x 1216 tokens).
-# Bounded: at most LLAMA_WS_MAX_STREAMS entries, least recently used evicted (a server that prefills on many torch streams would
-# otherwise pin that much per stream handle forever -- the pool has ~32 handles per device); ``release_llama_workspaces()`` drops all.
-# An evicted buffer goes back to the caching allocator, which keeps it stream-ordered for the stream it was allocated on; work
-# already enqueued on ANOTHER stream that used it is protected by ``record_stream`` below.
-LLAMA_WS_MAX_STREAMS = 4
+# Bounded PER DEVICE: at most LLAMA_WS_MAX_STREAMS entries per device (SLIME_LLAMA_WS_MAX_STREAMS overrides the default of 4), the
+# device's least recently used one evicted (a server that prefills on many torch streams would otherwise pin that much per stream
+# handle forever -- the pool has ~32 handles per device; a model split across GPUs does not evict another device's buffers);
+# ``release_llama_workspaces()`` drops all.  An evicted buffer goes back to the caching allocator.  It was allocated on the stream
+# it served (the key's stream was current when Workspace.get grew it) and only ever used there, so the allocator's own
+# allocation-stream ordering already keeps it from a new owner until that stream's queued work is done: no record_stream needed.
+LLAMA_WS_MAX_STREAMS = max(1, int(os.environ.get("SLIME_LLAMA_WS_MAX_STREAMS", "4")))
 _LLAMA_WS: "collections.OrderedDict[tuple, Workspace]" = collections.OrderedDict()
 _LLAMA_WS_LOCK = threading.Lock()
 
@@ -860,10 +865,9 @@ def _llama_workspace() -> Workspace:
         if ws is None:
             ws = _LLAMA_WS[key] = Workspace()
         _LLAMA_WS.move_to_end(key)
-        while len(_LLAMA_WS) > LLAMA_WS_MAX_STREAMS:
-            _, old = _LLAMA_WS.popitem(last=False)
-            if old.buf is not None:
-                old.buf.record_stream(st)               # never handed to a new owner before this stream's queued work is done
+        mine = [k for k in _LLAMA_WS if k[0] == key[0]]            # this device's entries, least recently used first
+        for k in mine[: max(0, len(mine) - LLAMA_WS_MAX_STREAMS)]:
+            del _LLAMA_WS[k]
         return ws
 
 

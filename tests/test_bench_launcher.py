@@ -71,3 +71,41 @@ def test_pmc_traffic_reports_a_missing_kernel_without_aborting():
     assert t is None and src.startswith("profiles/") and err and "no_such_kernel" in err
     t, src, head, err = bench.pmc_traffic("no_such_kernel<BF16>", profiled_shape=False)
     assert t is None and err is None and src.startswith("not profiled")
+
+
+def test_box_sampler_reduces_samples_per_phase(monkeypatch):
+    """bench.py's BoxSampler (round 6): samples carry the phase that was current, summary() reduces per phase and lifts the timed
+    region's means to the flat keys the bench line promises; a box without any telemetry source yields source None, no exception."""
+    import time
+    bench = _load_bench()
+    vals = iter(range(10_000))
+
+    def fake_open(self, idx):
+        self.source = "fake"
+        return lambda: {"sclk_mhz": 2000.0 + next(vals) % 3, "mclk_mhz": 1900.0, "power_w": 1000.0, "temp_c": None}
+    monkeypatch.setattr(bench.BoxSampler, "_open", fake_open)
+    b = bench.BoxSampler(0, period=0.002)
+    b.mark("idle"); time.sleep(0.03)
+    b.mark("timed"); time.sleep(0.05)
+    b.mark("after"); time.sleep(0.01)
+    b.stop()
+    s = b.summary(("idle", "timed", "after", "never"))
+    assert s["source"] == "fake" and s["timed"]["samples"] >= 5 and s["never"]["samples"] == 0
+    assert 2000.0 <= s["sclk_mhz_timed"] <= 2002.0 and s["power_w_timed"] == 1000.0 and "temp_c_timed" not in s
+    assert s["timed"]["sclk_mhz"]["min"] >= 2000.0 and s["timed"]["sclk_mhz"]["max"] <= 2002.0
+    monkeypatch.setattr(bench.BoxSampler, "_open", lambda self, idx: None)
+    none = bench.BoxSampler(0)
+    none.mark("timed"); none.stop()
+    assert none.summary(("timed",))["source"] is None
+    # _num: amdsmi hands back ints, "N/A" strings and per-XCD lists (0xFFFF = not populated)
+    assert bench.BoxSampler._num(1950) == 1950.0 and bench.BoxSampler._num("N/A") is None
+    assert bench.BoxSampler._num([2000, 1900, 65535, "N/A"]) == 1950.0 and bench.BoxSampler._num([]) is None
+
+
+def test_box_sampler_real_sources_never_raise():
+    """On this GPU-less container every source is missing or refuses (amdsmi: driver not loaded): the constructor falls through."""
+    bench = _load_bench()
+    b = bench.BoxSampler(0)
+    b.mark("timed"); b.stop()
+    s = b.summary(("timed",))
+    assert "source" in s

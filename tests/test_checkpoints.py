@@ -150,3 +150,58 @@ def test_loaded_files_run_on_the_gpu_vs_oracle(tmp_path, dtype):
     ref = O.encode_image(W.strip_tower_prefix(tsd), asd, W.TINY, W.ADAPTER_TINY, px, (672, 672))
     tol = {torch.float16: 6e-3, torch.bfloat16: 3e-2}[dtype]
     assert rel_l2(glob.cpu(), ref["global"]) < tol and rel_l2(merged.cpu(), ref["merged"]) < tol
+
+
+def _load_verify_tool():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("slime_verify_checkpoint", os.path.join(root, "tools", "verify_checkpoint.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_verify_checkpoint_tool_cpu_part(tmp_path, capsys):
+    """tools/verify_checkpoint.py on an HF-format directory written from make_tower_state_dict + adapter files
+    with the LoRA prefixes: the product loaders, the fp32 oracle, and the per-layer outlier statistic -- a channel planted at x60
+    in layer 0's fc2 bias must show up as THE argmax channel of hidden state 1 with max / rms far above the unplanted states."""
+    from slime_amd import weights as W
+    tsd = W.make_tower_state_dict(W.TINY, seed=33)
+    planted = 37
+    tsd["vision_model.encoder.layers.0.mlp.fc2.bias"] = tsd["vision_model.encoder.layers.0.mlp.fc2.bias"].clone()
+    tsd["vision_model.encoder.layers.0.mlp.fc2.bias"][planted] = 60.0
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=34)
+    tdir, adir = tmp_path / "clip", tmp_path / "ckpt"
+    tdir.mkdir(); adir.mkdir()
+    _write_hf_dir(tdir, tsd, W.TINY, True)
+    _adapter_files(adir, asd, "lora")
+    tool = _load_verify_tool()
+    out = tmp_path / "report.json"
+    rep = tool.main([str(tdir), str(adir), "--cpu-only", "--json", str(out)])
+    text = capsys.readouterr().out
+    assert rep["crops"] == 5 and rep["hip"] is None and "HIP path: skipped (--cpu-only)" in text
+    assert len(rep["outliers"]) == W.TINY.num_hidden_layers                       # hidden_states[0 .. L-1]: what select_layer -2 needs
+    s0, s1 = rep["outliers"][0], rep["outliers"][1]
+    assert s1["argmax_channel"] == planted and s1["max_abs"] > 50 and s1["max_over_rms"] > 2 * s0["max_over_rms"] and s1["channels_over_20_rms"] <= 2
+    assert json.load(open(out))["outliers"] == rep["outliers"]
+    assert any("tensors from" in n for n in rep["notes"])
+    # without adapter files: the tower is real, the adapter a seeded stand-in, and the report says so
+    rep2 = tool.main([str(tdir), "--cpu-only", "--size", "336", "336"])
+    assert rep2["crops"] == 3 and any("NO checkpoint given" in n for n in rep2["notes"])
+
+
+@pytest.mark.gpu
+def test_verify_checkpoint_tool_full(tmp_path):
+    """The same tool end to end on the GPU box: HIP fp16 / bf16 against the oracle on the loaded files, per stage and per hidden state."""
+    from slime_amd import weights as W
+    tsd = W.make_tower_state_dict(W.TINY, seed=33)
+    asd = W.make_adapter_state_dict(W.ADAPTER_TINY, seed=34)
+    tdir, adir = tmp_path / "clip", tmp_path / "ckpt"
+    tdir.mkdir(); adir.mkdir()
+    _write_hf_dir(tdir, tsd, W.TINY, False)
+    _adapter_files(adir, asd, "pretrain")
+    rep = _load_verify_tool().main([str(tdir), str(adir)])
+    for key, tol in (("fp16", 3e-3), ("bf16", 2e-2)):
+        r = rep["hip"][key]
+        assert r["tower"] < tol and r["global"] < tol and r["merged_local"] < tol and r["compressed"] < tol, (key, r)
+        assert len(r["hidden_states"]) == W.TINY.num_hidden_layers and max(r["hidden_states"]) < tol

@@ -160,3 +160,17 @@ def test_head_shard_weight_slices_cover_the_layer():
     with pytest.raises(ValueError):
         shard_llama_attention_weights(wq, wk, wv, wo, HQ, HKV, 3, 0)
     assert head_shard_bytes(9280) == 9280 * 4096 * 2
+
+
+def test_predicted_step_model_matches_design_table():
+    """slime_amd.dist.predicted_step_ms (what bench.py prints beside the measured `strong` object): the committed MI355X latency
+    curve + transfer model + adapter share reproduce DESIGN.md section 7's strong-scaling rows and are monotone in the rank count."""
+    from slime_amd import dist as D
+    t = {n: D.predicted_step_ms(40, 5, n) for n in (1, 2, 4, 8)}
+    assert t[1] > t[2] > t[4] > t[8] > 0
+    assert abs(t[1] - (D.tower_ms(40) + D.adapter_ms(8))) < 1e-9                # one GPU: no gather
+    assert abs(t[8] - (D.tower_ms(5) + D.gather_ms(5, 8) + D.adapter_ms(1))) < 1e-9
+    assert 3.5 < t[1] / t[8] < 5.0                                               # 5 crops per rank run far below the 40-crop rate
+    c3 = {n: D.predicted_step_ms(68, 17, n) for n in (1, 8)}
+    assert 4.0 < c3[1] / c3[8] < 5.5
+    assert D.adapter_ms(0) == 0.0 and D.adapter_ms(3) == (D.ADAPTER_MS[2] + D.ADAPTER_MS[4]) / 2 and D.adapter_ms(16) == 2 * D.ADAPTER_MS[8]

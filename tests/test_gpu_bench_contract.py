@@ -40,6 +40,19 @@ def test_bench_prints_one_contract_line():
     assert c["kind"] == "port" and c["unit"] == "crops/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
     assert "traffic_error" not in r, r.get("traffic_error")       # the committed PMC summary knows the dominant kernel of this build
     assert d["ms_per_step_rank_min"] <= d["ms_per_step"] + 1e-3 and d["ms_per_step_rank_max"] >= d["ms_per_step_rank_min"]
+    # round 6: the line says what box it ran on and how repeatable it was
+    rep = d["ms_per_step_repeats"]
+    assert len(rep) == 3 and rep[0] == d["ms_per_step"] and max(rep) / min(rep) < 1.10, rep      # headline = the FIRST K steps; repeats within 10 %
+    box = d["box"]
+    assert "source" in box and "MI3" in box["device"]
+    if box["source"] is not None:                                 # a box with a readable telemetry source: the timed region was sampled
+        assert box["timed"]["samples"] >= 2 and 500 < box["sclk_mhz_timed"] < 3000 and 50 < box["power_w_timed"] < 2000, box
+        assert box["idle"]["samples"] >= 1
+    pm = d["path_mfma"]
+    cal = pm["mfma_stream_calibration"]                           # THIS box's bare MFMA stream, measured in this run (no constant)
+    assert pm["power_capped_mfma_stream_tflops"] == cal["tflops"] and 800 < cal["tflops"] <= 2600 and cal["launches"] >= 3, cal
+    assert abs(pm["frac_of_power_capped_mfma_stream"] - pm["algorithmic_tflops"] / cal["tflops"]) < 2e-3
+    assert pm["frac_of_peak"] < pm["frac_of_power_capped_mfma_stream"] < 1.0
 
 
 def _bench(args, env=None, timeout=900):
@@ -69,6 +82,15 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["config"]["crops_per_gpu"] == 40 and d["config"]["images_per_step"] == 16
     assert abs(d["value"] - 80 * 1e3 / d["ms_per_step"]) / d["value"] < 0.01          # whole-job rate: 2 x 40 crops per step
     assert d["ms_per_step_rank_min"] <= d["ms_per_step_rank_max"] and abs(d["ms_per_step_rank_max"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+    # round 6: ONE driver command returns both curves -- the weak headline says its gather feeds nobody, and the
+    # same run times north_star's data flow (the same 40 crops sharded over the ranks, all-gather BEFORE the adapter) as `strong`
+    assert d["config"]["gather_consumed"] is False
+    s = d["strong"]
+    assert s["scaling"] == "strong" and s["gather_consumed"] is True and s["crops_per_rank_padded"] == 20 and s["images_owned_by_rank0"] == 4
+    assert s["ms_per_step"] > 0 and abs(s["value"] - 40 * 1e3 / s["ms_per_step"]) / s["value"] < 0.01      # whole job: the 40 crops, once
+    assert s["ms_per_step_rank_min"] <= s["ms_per_step_rank_max"]
+    assert s["predicted_ms_per_step"] > 0 and 1.0 < s["speedup_vs_n1_predicted"] < 2.0                      # two ranks: below 2x by the model
+    assert len(d["ms_per_step_repeats"]) == 3 and len(d["box"].get("ranks_timed", [0, 0])) == 2
 
 
 def test_bench_refuses_more_gpus_than_the_node_has():

@@ -1,7 +1,7 @@
 """GPU tests of the reference-shaped plugin API (CLIPVisionTower, build_vision_projector,
-build_vision_sampler, encode_images) against the CPU oracle.  Per-stage tolerances as in test_gpu_path.py
-(fp16 3e-3, bf16 1.5e-2, rel-L2 vs the fp32 oracle); end-of-chain tensors (pixels rounded to T -> tower ->
-post_qformer -> MLP) are allowed 2x that."""
+build_vision_sampler, encode_images) against the CPU oracle.  Per-stage tolerances are test_gpu_path.py's
+(fp16 1.2e-3, bf16 8e-3, rel-L2 vs the fp32 oracle; round 6: they were 3e-3 / 1.5e-2 here); end-of-chain tensors
+(pixels rounded to T -> tower -> post_qformer -> MLP) are allowed 1.5x that."""
 from types import SimpleNamespace
 
 import numpy as np
@@ -13,7 +13,7 @@ from PIL import Image
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
-TOL = {torch.float16: 3e-3, torch.bfloat16: 1.5e-2}
+TOL = {torch.float16: 1.2e-3, torch.bfloat16: 8e-3}
 PIN = "[(336, 672), (672, 336), (672, 672), (1008, 336), (336, 1008)]"
 
 
@@ -184,7 +184,7 @@ def test_encode_images_vs_oracle(dev, dtype, sizes):
         # router: the oracle's rule applied to the DEVICE's merged tokens must select the same set, up to
         # near-ties at the top-p cut (the scores agree to ~1e-6, the selection is discontinuous)
         merged_dev = pairs[i][1].cpu()
-        assert rel_l2(merged_dev, ref["merged"]) < TOL[dtype] * 2
+        assert rel_l2(merged_dev, ref["merged"]) < TOL[dtype] * 1.5
         keep_ref = O.router_select(O.router_cosine_scores(merged_dev, text[i].float().cpu(), tmask[i].cpu()), 0.95, 1.0)
         rows = out[577:]
         assert abs(rows.shape[0] - keep_ref.numel()) <= 2
@@ -197,7 +197,7 @@ def test_encode_images_vs_oracle(dev, dtype, sizes):
     # router-free form used by bench.py
     for i, s in enumerate(sizes):
         ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[i], s)
-        assert rel_l2(pairs[i][1].cpu(), ref["merged"]) < TOL[dtype] * 2
+        assert rel_l2(pairs[i][1].cpu(), ref["merged"]) < TOL[dtype] * 1.5
 
 
 def test_gpu_slicer_matches_pil_path(dev):
@@ -244,7 +244,7 @@ def test_encode_images_flags_and_mask(dev):
     enc_f, _, _ = _tiny_encoder(dev, dtype, embed=embed, mm_patch_merge_type="flat")
     pairs = enc_f.encode_visual(images[:5], [5], [(672, 672)], merge="flat")
     ref = O.encode_image(tsd, asd, W.TINY, W.ADAPTER_TINY, px[0], (672, 672), merge="flat")
-    assert rel_l2(pairs[0][1].cpu(), ref["merged"]) < TOL[dtype] * 2
+    assert rel_l2(pairs[0][1].cpu(), ref["merged"]) < TOL[dtype] * 1.5
     # use_global_only / use_local_only
     enc_g, _, _ = _tiny_encoder(dev, dtype, embed=embed, use_global_only=True)
     fg, _ = enc_g.encode_images(images[:5], input_ids=ids[:1], split_sizes=[5], attention_mask=am[:1], image_sizes=[(672, 672)])
@@ -257,10 +257,10 @@ def test_encode_images_flags_and_mask(dev):
     assert not enc_n.get_model().has_sampler
     plain, _ = enc_n.encode_images(images[:3])
     ref_plain = O.gated_block_forward(W.sub_state(asd, "mm_projector."), O.tower_forward(tsd, W.TINY, px[0][:3]), 1)
-    assert plain.shape == (3, 576, 256) and rel_l2(plain.float().cpu(), ref_plain) < TOL[dtype] * 2
+    assert plain.shape == (3, 576, 256) and rel_l2(plain.float().cpu(), ref_plain) < TOL[dtype] * 1.5
     lst, ss = enc_n.encode_images(images[:5], split_sizes=[2, 3])
     assert ss == [2, 3] and [t.shape[0] for t in lst] == [2, 3]
-    assert rel_l2(torch.cat(lst).float().cpu()[:3], ref_plain) < TOL[dtype] * 2
+    assert rel_l2(torch.cat(lst).float().cpu()[:3], ref_plain) < TOL[dtype] * 1.5
 
 
 def test_tower_list_edge_cases(dev):
@@ -394,7 +394,7 @@ def test_cfg3_layout_17_crops_vs_oracle(dev, dtype):
         loc = O.mlp_projector(W.sub_state(asd, "mm_projector."), comp)
         merged = O.spatial_merge(loc, nw, nh, 12)
         assert rel_l2(tokens[i, :576], glob) < TOL[dtype] * 1.5
-        assert rel_l2(tokens[i, 576:], merged) < TOL[dtype] * 2
+        assert rel_l2(tokens[i, 576:], merged) < TOL[dtype] * 1.5
 
 
 def test_stacked_local_crops_of_576_take_the_mlp(dev):
@@ -465,3 +465,36 @@ def test_router_exact_on_separated_scores_and_batched_equals_single(dev):
     assert ragged[1].numel() == 0
     assert torch.equal(ragged[0], ops.router_topp(tokens[0, P:].contiguous(), text[0], None, 0.9, 0.7))
     assert torch.equal(ragged[2], ops.router_topp(tokens[2, P:P + 144].contiguous(), text[2], None, 0.9, 0.7))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_config1_plugin_api_one_crop_full_size(dev, dtype):
+    """BASELINE config 1 through the reference-shaped plugin API at CLIP-ViT-L/14-336 / SliME-8B dims: one 336 x 336 image,
+    ``image_aspect_ratio='pad'`` (mm_utils.py:234-238 -> ONE crop), ``CLIPVisionTower.forward`` tensor branch
+    (clip_encoder.py:46-58) and ``encode_images`` without split sizes (llava_arch.py:261-267: GatedBlock on the global
+    view), against the fp32 oracle on the same pixels.  fp16 meets north_star's 1e-3 at the projector output."""
+    from slime_amd import weights as W, mm_utils as M
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
+    from oracle import slime_oracle as O
+    cfg = default_slime_config("synthetic:1234", image_aspect_ratio="pad")
+    tower_sd = W.make_tower_state_dict(W.CLIP_L_336, seed=1234)
+    adapter_sd = W.make_adapter_state_dict(W.ADAPTER_8B, seed=4321)
+    enc = SlimeVisualEncoder(cfg)
+    enc.load_visual_state(tower_sd, adapter_sd)
+    enc.to(dev)
+    enc.get_vision_tower().vision_tower.to(dtype)
+    tower = enc.get_vision_tower()
+    img = Image.fromarray(np.random.default_rng(3).integers(0, 256, (336, 336, 3), dtype=np.uint8), "RGB")
+    px = M.process_images([img], tower.image_processor, cfg)
+    assert px.shape == (1, 3, 336, 336)                        # 'pad' yields one crop ('anyres' would yield 3: SURVEY a-1)
+    tsd = W.strip_tower_prefix(tower_sd)
+    ref_t = O.tower_forward(tsd, W.CLIP_L_336, px)
+    ref_g = O.gated_block_forward(W.sub_state(adapter_sd, "mm_projector."), ref_t[0], W.ADAPTER_8B.num_heads)
+    feats = tower(px.to(dev).to(dtype))
+    assert feats.shape == (1, 576, 1024) and feats.dtype == dtype
+    assert rel_l2(feats.float().cpu(), ref_t) < TOL[dtype]
+    out, ss = enc.encode_images(px.to(dev).to(dtype))
+    assert ss is None and out.shape == (1, 576, 4096) and out.dtype == dtype
+    err = rel_l2(out[0].float().cpu(), ref_g)
+    print(f"config 1 through the plugin API, {dtype}: tower {rel_l2(feats.float().cpu(), ref_t):.3e} projector {err:.3e}")
+    assert err <= {torch.float16: 1e-3, torch.bfloat16: 1.2e-2}[dtype], err

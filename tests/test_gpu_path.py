@@ -148,7 +148,9 @@ def test_full_size_shard_invariance(dev):
     again = vm.encode(px)
     assert full.shape == (40, 576, 1024) and torch.isfinite(full.float()).all()
     assert torch.equal(full, again)
-    for shard in (5, 20):
+    # 1 / 2 / 3 crops: the 64x64 ring tile (grids that leave half the CUs without a 128x128 workgroup) against the direct-B /
+    # ping-pong kernels of the 20-crop halves; 1 crop is BASELINE config 1's launch shape
+    for shard in (1, 2, 3, 5, 20):
         parts = torch.cat([vm.encode(px[i:i + shard].contiguous()) for i in range(0, 40, shard)])
         assert torch.equal(parts, full), shard
 
@@ -182,6 +184,43 @@ def test_production_half_batch_tower_vs_oracle(dev, full20, dtype):
     assert float(per_crop.max()) < TOL[dtype] * 1.3, per_crop
     per_tok = ((out - ref).norm(dim=-1) / ref.norm(dim=-1)).flatten()
     assert float(per_tok.max()) < TOL[dtype] * 4, "no single token far off (a wrong tile would hide in the aggregate)"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_config1_single_crop_global_only_vs_oracle(dev, full20, dtype):
+    """BASELINE config 1 at full size on the HIP path: ONE 336 x 336 crop (global view only, batch 1) through the ViT-L/14-336
+    tower -- every GEMM on the 64x64 ring tile, attention over 16 (crop, head) pairs -- and the GatedBlock on that global view
+    (clip_encoder.py:46-58 tensor branch; llava_arch.py:261-267 plain batch; projector/builder.py:179-209), against the fp32
+    oracle directly.  north_star's 1e-3 is asserted at `global` for fp16; bf16 is held to its stated end-of-chain bound.  The
+    1-crop pass must also equal crop 0 of the 20-crop pass bit for bit (shard invariance at the smallest grid)."""
+    from slime_amd import ops, weights as W
+    from oracle import slime_oracle as O
+    tsd, asd, px, ref_feats = full20
+    A = W.ADAPTER_8B
+    proj_sd = W.sub_state(asd, "mm_projector.")
+    pt = ops.pack_tower(tsd, W.CLIP_L_336, dtype, dev)
+    one = ops.tower_forward(pt, px[:1].to(dev), out_dtype=torch.float32)
+    assert one.shape == (1, 576, 1024)
+    assert rel_l2(one.cpu(), ref_feats[:1]) < TOL[dtype]
+    per_tok = ((one.cpu() - ref_feats[:1]).norm(dim=-1) / ref_feats[:1].norm(dim=-1)).flatten()
+    assert float(per_tok.max()) < TOL[dtype] * 4
+    batch = ops.tower_forward(pt, px.to(dev), out_dtype=torch.float32)
+    assert torch.equal(one, batch[:1])
+    g_ref = O.gated_block_forward(proj_sd, ref_feats[0], A.num_heads)
+    pg = ops.pack_gated(proj_sd, A, dtype, dev)
+    feats_t = ops.tower_forward(pt, px[:1].to(dev), out_dtype=dtype)
+    bound = {torch.float16: 1e-3, torch.bfloat16: 1.2e-2}[dtype]
+    # fused adapter with no local crops (one C-ABI call on the tower's 16-bit features) and the per-module GatedBlock launch sequence
+    fused = ops.adapter_forward(pg, None, feats_t, 1, 0, 1, 1, False, -1, torch.float32)
+    assert fused.shape == (1, 576, 4096)
+    eg = rel_l2(fused[0].cpu(), g_ref)
+    print(f"config 1 (1 crop, global only) {dtype}: tower {rel_l2(one.cpu(), ref_feats[:1]):.3e} global {eg:.3e}")
+    assert eg <= bound, (dtype, eg)
+    mod = ops.gated_forward(pg, one)[0]
+    assert rel_l2(mod.cpu(), g_ref) <= bound
+    for lg in (0, 1):                                     # stage-1 expert selection (projector/builder.py:198-201)
+        e = ops.gated_forward(pg, one, learnable_gated=lg)[0]
+        assert rel_l2(e.cpu(), O.gated_block_forward(proj_sd, ref_feats[0], A.num_heads, learnable_gated=lg)) <= bound
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

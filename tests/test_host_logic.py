@@ -28,12 +28,40 @@ def test_library_exports_exactly_the_header():
     assert len(syms) >= 30
     for s in syms:
         assert hasattr(lib, s), f"libslime_hip.so does not export {s}"
-    assert lib.slime_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.slime_abi_version() == _lib.ABI_VERSION == 6
     assert _exported(_lib.LIB_PATH) == syms
     assert set(_lib._SIGNATURES) == syms, "slime_amd/_lib.py binds exactly the header's functions"
     if os.path.exists(_lib.DIAG_LIB_PATH):
         extra = _exported(_lib.DIAG_LIB_PATH) - syms
         assert extra == set(_lib._DIAG_SIGNATURES), extra
+
+
+def test_vit_check_refuses_geometries_the_front_end_cannot_run():
+    """the fused front end's limits are checked when a tower is PACKED (slime_vit_check, host-only -- no GPU needed), with
+    the limit named: CLIP-L/14-336 and -224 pass, a 448 / 14 tower (32 patches per side), a 340-pixel image (not a multiple of 8
+    ... nor of the patch) and head_dim 80 do not."""
+    import ctypes as C
+    from slime_amd import _lib
+    lib = _lib.load()
+
+    def desc(image=336, patch=14, hidden=1024, heads=16, inter=4096):
+        d = _lib.VitDesc()
+        d.hidden, d.inter, d.heads, d.layers_run, d.image, d.patch = hidden, inter, heads, 2, image, patch
+        d.kpad, d.dtype, d.eps = (3 * patch * patch + 63) // 64 * 64, _lib.BF16, 1e-5
+        for name, _ in _lib.VitDesc._fields_:
+            if isinstance(getattr(d, name), (type(None),)) and name != "patch_w":
+                setattr(d, name, 0x1000)                          # any non-null address: the check never dereferences
+        return d
+
+    assert lib.slime_vit_check(C.byref(desc())) == 0
+    assert lib.slime_vit_check(C.byref(desc(image=224))) == 0
+    for bad, word in ((desc(image=448), "patches per side"), (desc(image=340, patch=10), "multiple of the patch"),
+                      (desc(heads=12), "head_dim"), (desc(hidden=512, heads=8), "hidden=512")):
+        assert lib.slime_vit_check(C.byref(bad)) == -1
+        assert word in lib.slime_last_error().decode(), lib.slime_last_error()
+    missing = desc()
+    missing.w_fc2, missing.w_fc2_frag = None, None
+    assert lib.slime_vit_check(C.byref(missing)) == -1 and "missing layer weights" in lib.slime_last_error().decode()
 
 
 def test_grid_tables_match_reference():
