@@ -553,7 +553,7 @@ def main():
         my_images = list(range(IMAGES)) if args.config == 5 else D.image_shard(IMAGES, world, rank)
         lo_i, hi_i = (my_images[0], my_images[-1] + 1) if my_images else (0, 0)
         per_rank_crops = -(-n_step // world)
-        chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world, device_name=torch.cuda.get_device_name(dev),
+        chunk = {"chunked": 3, "auto": D.choose_chunk(per_rank_crops, world, device_name=D.device_label(dev),
                                                       model="CLIP-ViT-L/14-336", dtype="bf16")}.get(gather_mode, 0)
 
         def tower_fn(x):
@@ -779,7 +779,7 @@ def main():
         box.mark("after")
         time.sleep(0.1)
         box.stop()
-        res["box"] = {"device": torch.cuda.get_device_name(dev), "cus": torch.cuda.get_device_properties(dev).multi_processor_count,
+        res["box"] = {"device": D.device_label(dev), "cus": torch.cuda.get_device_properties(dev).multi_processor_count,
                       **box.summary(("idle", "warmup", "timed", "repeat", "strong", "probe", "calibration", "fp16", "after")),
                       **({"ranks_timed": box_ranks} if box_ranks else {}),
                       "what": "this rank's GPU while the bench ran: idle = context up, nothing running; timed = the headline K steps; repeat = the two repeats; "

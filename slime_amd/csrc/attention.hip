@@ -329,6 +329,13 @@ __device__ __forceinline__ u32x2 lds_tr16_asm(unsigned addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
     return r;
 }
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_b64_asm(unsigned addr) {       // plain 8-byte read (timing ablation VABL: see attn64r_pass)
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
 __device__ __forceinline__ unsigned lds_addr(const char* p) {
     return (unsigned)(size_t)((__attribute__((address_space(3))) const char*)p);
 }
@@ -606,7 +613,11 @@ __global__ void __launch_bounds__(512) attn64_kernel(AttnArgs a) {
 #ifndef SLIME_OPT_ATTN_SHORT_TAIL
 #define SLIME_OPT_ATTN_SHORT_TAIL 1
 #endif
-template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3, int RING = 0>
+// VABL (diagnostic build, variant 40; WRONG results, right timing): the eight ds_read_b64_tr_b16 V^T reads of a kv step are replaced
+// by eight plain ds_read_b64 of the same step's 4 KiB at lane-linear addresses (64 lanes x 8 B = every bank exactly once per pass:
+// conflict free) -- the same number of LDS instructions, bytes and waits without the 2-way bank conflict.  The difference to the
+// product kernel is the exact price of that conflict (VERDICT r5 item 5 i).
+template <typename T, int NSUB, bool RESIDENT, int NW = 8, bool KPF = false, int AHEAD = 3, int RING = 0, int VABL = 0>
 __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, const int b, const int h, const int sb0,
                                              unsigned long long* t_first = nullptr) {    // diagnostic: when the first granule was ready
     constexpr int DH = 64, RB = 128, KS = 2, DT = 4, KC = 608;
@@ -747,6 +758,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
         // like the 12-wave variant below: the kernel is not bound by exposed LDS latency.
         u32x4 kf[2][KS];
         unsigned kring = 0, vring = 0;                        // RING: byte offset of the current 32-row step inside the ring (wave-uniform)
+        [[maybe_unused]] unsigned vabl = lds_addr(Vlds) + lane * 8;   // VABL: lane-linear (conflict-free) read address of the current step
         auto k_request = [&]() {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -781,11 +793,20 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
             // 4 exponentials per query and K = 16 MFMAs (half the matrix time) instead of a 32-key step that is 1/32 useful
             constexpr bool SHORT = decltype(short_c)::value;
             u32x2 v0[DT], v1[DT];
+            if constexpr (VABL != 0) {
+                static_assert(DT == 4 && RING == 0, "ablation: CLIP shape, resident panel");
+                v0[0] = lds_b64_asm<0>(vabl); v0[1] = lds_b64_asm<512>(vabl); v0[2] = lds_b64_asm<1024>(vabl); v0[3] = lds_b64_asm<1536>(vabl);
+                if constexpr (!SHORT) {
+                    v1[0] = lds_b64_asm<2048>(vabl); v1[1] = lds_b64_asm<2560>(vabl); v1[2] = lds_b64_asm<3072>(vabl); v1[3] = lds_b64_asm<3584>(vabl);
+                }
+                vabl += 32 * RB;
+            } else {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1] + vring) : lds_tr16_asm<0>(vptr[dt >> 1] + vring);
-                if constexpr (!SHORT)
-                    v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1] + vring) : lds_tr16_asm<16 * RB>(vptr[dt >> 1] + vring);
+                for (int dt = 0; dt < DT; ++dt) {
+                    v0[dt] = (dt & 1) ? lds_tr16_asm<8>(vptr[dt >> 1] + vring) : lds_tr16_asm<0>(vptr[dt >> 1] + vring);
+                    if constexpr (!SHORT)
+                        v1[dt] = (dt & 1) ? lds_tr16_asm<16 * RB + 8>(vptr[dt >> 1] + vring) : lds_tr16_asm<16 * RB>(vptr[dt >> 1] + vring);
+                }
             }
             if constexpr (RING) vring = (vring + 32 * RB) & RMASK;
             else { vptr[0] += 32 * RB; vptr[1] += 32 * RB; }
@@ -930,7 +951,7 @@ __device__ __forceinline__ void attn64r_pass(const AttnArgs& a, char* smem, cons
 #ifndef SLIME_OPT_ATTN_PAIR
 #define SLIME_OPT_ATTN_PAIR 1
 #endif
-template <typename T, int AHEAD = 3>
+template <typename T, int AHEAD = 3, int VABL = 0>
 __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 8, P1 = 3 * NW;                        // pass 1: <= 3 sub-blocks per wave
@@ -963,10 +984,10 @@ __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
         const int cnt = base + (wave < rem ? 1 : 0);
         const int sb0 = wg_sb0 + wave * base + min(wave, rem);
         switch (cnt) {
-            case 0: attn64r_pass<T, 0, false, NW, false, AHEAD>(a, smem, b, h, sb0); break;
-            case 1: attn64r_pass<T, 1, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
-            case 2: attn64r_pass<T, 2, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
-            default: attn64r_pass<T, 3, false, NW, false, AHEAD>(a, smem, b, h, sb0, tfp); break;
+            case 0: attn64r_pass<T, 0, false, NW, false, AHEAD, 0, VABL>(a, smem, b, h, sb0); break;
+            case 1: attn64r_pass<T, 1, false, NW, false, AHEAD, 0, VABL>(a, smem, b, h, sb0, tfp); break;
+            case 2: attn64r_pass<T, 2, false, NW, false, AHEAD, 0, VABL>(a, smem, b, h, sb0, tfp); break;
+            default: attn64r_pass<T, 3, false, NW, false, AHEAD, 0, VABL>(a, smem, b, h, sb0, tfp); break;
         }
     }
 #ifdef SLIME_DIAG
@@ -981,8 +1002,8 @@ __global__ void __launch_bounds__(512) attn64r_kernel(AttnArgs a) {
         const int sb0 = wg_sb0 + n1 + rw * base + min(rw, rem);
         switch (cnt) {
             case 0: break;
-            case 1: attn64r_pass<T, 1, true>(a, smem, b, h, sb0); break;
-            default: attn64r_pass<T, 2, true>(a, smem, b, h, sb0); break;
+            case 1: attn64r_pass<T, 1, true, NW, false, 3, 0, VABL>(a, smem, b, h, sb0); break;
+            default: attn64r_pass<T, 2, true, NW, false, 3, 0, VABL>(a, smem, b, h, sb0); break;
         }
     }
 #ifdef SLIME_DIAG
@@ -1089,11 +1110,11 @@ static int launch_attn64g(const AttnArgs& a0, int batch, hipStream_t stream) {
 }
 #endif  // SLIME_DIAG
 
-template <typename T, int AHEAD = 3>
+template <typename T, int AHEAD = 3, int VABL = 0>
 static int launch_attn64r(const AttnArgs& a0, int batch, hipStream_t stream) {
     AttnArgs a = a0;
     constexpr int LDS = 2 * 608 * 128;
-    auto kern = attn64r_kernel<T, AHEAD>;
+    auto kern = attn64r_kernel<T, AHEAD, VABL>;
     SLIME_SET_LDS_ONCE(kern, LDS, "attention");
     const int total_sb = (a.n_q + 15) / 16;
     int qsplit = (total_sb + 39) / 40;                        // <= 3 + 2 sub-blocks per wave, 8 waves
@@ -1179,6 +1200,8 @@ extern "C" int slime_attention(const void* q, long q_bs, long q_rs, const void* 
             default: return launch_attn64r<BF16, 16>(a, batch, s);
         }
     }
+    if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 40 && dtype == SLIME_BF16 && !g_attn_dbg)
+        return launch_attn64r<BF16, 3, 1>(a, batch, s);      // round 6 timing ablation: conflict-free plain reads instead of the V^T transpose reads (wrong results)
     if (head_dim == 64 && n_kv <= 608 && n_kv >= 321 && g_attn_variant == 17 && g_attn_dbg) {   // attn64r with one stamp record per workgroup
         if (dtype == SLIME_F16) return launch_attn64r<F16>(a, batch, s);
         return launch_attn64r<BF16>(a, batch, s);

@@ -1195,6 +1195,9 @@ constexpr int db_younger(int mi, int nj, int ks, bool more, bool refill) {
     return c;
 }
 
+// MI = 6 (round 6, tile 19): 96 x 256 tile for the K = 1024 launches whose 128-row grid quantises badly at the 20-crop half batch
+// (M = 11540: q/k/v 1092 workgroups = 2.13 rounds of 512 slots -> 1452 = 2.84; out_proj 364 = 0.71 of a round -> 484 = 0.945): same
+// stream, 24 MFMAs per k-step and 3 DMA pieces per wave, db_younger() counts for any MI.  Same k order per accumulator: bit-identical.
 // MI = 8: 128 x 256 tile, two workgroups per CU (the product form).  MI = 4: 64 x 256 tile (64 accumulators), built into the diagnostic
 // library only (tile 13): tried for grids that do not give every CU a 128-row workgroup (rank shards of 5-9 crops, single images) and
 // measured SLOWER than the 128 x 128 lock-step kernel there (tower over 5 crops 3.70 -> 3.95 ms with fc2 on it, 9 crops 4.84 -> 5.07;
@@ -1203,7 +1206,7 @@ constexpr int db_younger(int mi, int nj, int ks, bool more, bool refill) {
 template <typename T, int EPI, int KTAG, int MI>
 __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     constexpr int NJ = 4, BM = 16 * MI, BN = 256, BK = 64, A_BYTES = BM * BK * 2, AP = MI / 2;
-    static_assert(MI == 8 || MI == 4, "direct-B tile heights: 128 or 64 rows");
+    static_assert(MI == 8 || MI == 6 || MI == 4, "direct-B tile heights: 128, 96 or 64 rows");
     // BIAS_GELU_MIX_T: a tile holds TROWS = 64 tokens -- their rows of A in its upper half, of A2 in its lower half (epilogue_mix)
     constexpr bool MIX = EPI == SLIME_EPI_BIAS_GELU_MIX_T;
     static_assert(!MIX || MI == 8, "the mix epilogue pairs accumulator blocks i and i + 4 of a 128-row tile");
@@ -1241,7 +1244,8 @@ __global__ void __launch_bounds__(256, 2) gemm_db_kernel(GemmArgs g) {
     unsigned soff[AP];
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
-        const int row = ((wave + 4 * j) * 8 + lrow) & (TROWS - 1);    // MIX: pieces 8..15 (j >= AP / 2) hold the same tokens, read from A2
+        const int row0 = (wave + 4 * j) * 8 + lrow;                   // < BM by construction (AP = BM / 32 pieces per wave)
+        const int row = MIX ? (row0 & (TROWS - 1)) : row0;            // MIX: pieces 8..15 (j >= AP / 2) hold the same tokens, read from A2
         const int rl = min(row, g.M - 1 - m0);                       // clamp: rows past M re-read the last row
         soff[j] = (unsigned)rl * (unsigned)g.lda * 2u + lchunk * 16;
     }
@@ -2073,7 +2077,7 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 2) tile = 1;
     if ((!g.B || g.row_map) && (tile == 5 || tile == 6 || tile == 7 || tile == 8)) tile = 4;   // persistent / 32x32 ping-pong variants: row-major B only, no row map
     if ((tile == 1 || (tile >= 4 && tile != 15 && tile != 18)) && g.N % 256 != 0) tile = 3;
-    if ((tile == 12 || tile == 13) && !g.Bf) tile = tile == 13 ? 3 : 11;
+    if ((tile == 12 || tile == 13 || tile == 19) && !g.Bf) tile = tile == 13 ? 3 : 11;
     if (tile == 6 || tile == 8) tile = 7;
     if (tile == 7 && (EPI == SLIME_EPI_BIAS_RESID_F32_LN || EPI == SLIME_EPI_BIAS_RESID_T || EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN)) tile = 4;     // the 32x32 variant has neither epilogue
     if (tile == 7) return launch_pp32b<T, EPI>(g, stream);
@@ -2097,6 +2101,12 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 18) return launch_cfg<T, 64, 64, 4, 1, EPI, 2>(g, stream);        // 64 x 64, three-stage ring (the smallest grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
 #ifdef SLIME_DIAG
+    if (tile == 19) {                                             // round 6: 96-row direct-B tiles, K <= 1024-class launches of the tower only
+        if constexpr (EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T || EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN) {
+            if (g.Bf && g.K < 2048) return launch_db_k<T, EPI, 0, 6>(g, stream);
+        }
+        return launch_db<T, EPI, 8>(g, stream);
+    }
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
 #else
     if (tile == 13) return launch_db<T, EPI, 8>(g, stream);

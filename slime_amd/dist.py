@@ -66,9 +66,24 @@ def _dtype_key(x) -> str:
 
 
 def _device_key(x) -> str:
-    """'AMD Instinct MI355X' / 'MI355X' -> 'mi355x' (the part number is the key; an unrecognised name is compared whole)."""
-    m = re.search(r"\bmi\d+[a-z]*\b", str(x).lower())
-    return m.group(0) if m else str(x).strip().lower()
+    """'AMD Instinct MI355X' / 'MI355X' -> 'mi355x' (the part number is the key; an unrecognised name is compared whole).  Boxes whose
+    marketing name is missing from the driver's id table report 'AMD Radeon Graphics': ``device_label`` appends the ISA name and
+    the CU count, and 'gfx950' with 256 CUs is the MI355X."""
+    t = str(x).lower()
+    m = re.search(r"\bmi\d+[a-z]*\b", t)
+    if m:
+        return m.group(0)
+    if "gfx950" in t and re.search(r"\b256 cus\b", t):
+        return "mi355x"
+    return t.strip()
+
+
+def device_label(device=None) -> str:
+    """Name of the running GPU for the profile applicability check: torch's device name plus ISA and CU count
+    ('AMD Radeon Graphics gfx950 256 CUs' on boxes without the amdgpu.ids table)."""
+    p = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+    arch = str(getattr(p, "gcnArchName", "")).split(":")[0]
+    return f"{p.name} {arch} {p.multi_processor_count} CUs".strip()
 
 
 def _model_key(x) -> str:

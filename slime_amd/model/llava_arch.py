@@ -29,7 +29,7 @@ import torch
 import torch.nn as nn
 
 from .multimodal_encoder.builder import build_vision_tower
-from .multimodal_projector.builder import build_vision_projector, GatedBlock, _operand_dtype
+from .multimodal_projector.builder import build_vision_projector, GatedBlock, HipMlp, _operand_dtype
 from .multimodal_resampler.builder import build_vision_sampler
 from .. import ops
 from ..constants import IMAGE_TOKEN_INDEX, IGNORE_INDEX
@@ -65,14 +65,26 @@ def _uniform_layout(split_sizes, image_sizes, cfg, crop: int, merge_type: str):
     return (n_local, nw, nh, True) if nw * nh == n_local else None
 
 
-def _project_local(projector, comp: torch.Tensor) -> torch.Tensor:
+def _project_local(projector, comp: torch.Tensor, operand_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """``mm_projector`` on the compressed local crops [sum n_i, g*g, D] of a whole batch.  The reference calls the projector
     per image (n_i <= 7 crops), where GatedBlock.forward's test ``x.shape[0] != 576 and x.shape[1] != 576``
     (projector/builder.py:180-181) always takes the plain-MLP return; on the batch-stacked tensor dim 0 is sum n_i and may
     equal 576 by accident, so the MLP is called directly instead of through that shape test."""
+    kw = {"operand_dtype": operand_dtype} if operand_dtype is not None else {}
     if isinstance(projector, GatedBlock):
-        return projector.projection(comp, out_dtype=torch.float32)
+        return projector.projection(comp, out_dtype=torch.float32, **kw)
+    if isinstance(projector, HipMlp):
+        return projector(comp, out_dtype=torch.float32, **kw)
     return projector(comp, out_dtype=torch.float32)
+
+
+def _adapter_operand_dtype(model, images: torch.Tensor) -> dict:
+    """``{"operand_dtype": T}`` for the adapter modules that take the extension (GatedBlock, HipMlp, Resampler) when the call's
+    images are 16-bit: the reference's tower returns features in the input dtype and its adapter computes in it."""
+    if images.dtype not in (torch.bfloat16, torch.float16):
+        return {}
+    from .multimodal_resampler.sampler import Resampler
+    return {"operand_dtype": images.dtype} if isinstance(model.mm_projector, (GatedBlock, HipMlp, Resampler)) else {}
 
 
 def _require_inference(model) -> None:
@@ -254,11 +266,15 @@ class SlimeMetaForCausalLM(ABC):
             dev = feats.device
             g_idx, l_idx = _split_indices(split_sizes, dev)
             glob = loc = None
+            # the adapter's MFMA operands are of the IMAGES' 16-bit type, as in the reference (its tower hands the adapter features
+            # in the input dtype, clip_encoder.py:52,56) -- not of a default picked from the fp32 hand-over (round 6: an fp16 call
+            # into fp32 adapter parameters ran the adapter on bf16 operands)
+            T16 = _adapter_operand_dtype(model, images)
             if not use_local_only:
-                glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)             # [B,576,H]
+                glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32, **T16)      # [B,576,H]
             if not use_global_only:
-                comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)    # [sum n_i,144,D]
-                loc = _project_local(model.mm_projector, comp)                                   # [sum n_i,144,H]
+                comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32, **T16)   # [sum n_i,144,D]
+                loc = _project_local(model.mm_projector, comp, T16.get("operand_dtype"))         # [sum n_i,144,H]
             g = model.sampler.grid_size
             merged_list = []
             lstart = 0
@@ -304,14 +320,15 @@ class SlimeMetaForCausalLM(ABC):
                 outs.append(torch.cat(pieces, dim=0).to(out_dtype).unsqueeze(0))
             return outs, split_sizes
 
+        T16 = _adapter_operand_dtype(model, images)
         if split_sizes is not None:                                               # no sampler: per-image lists
             feats = tower(images, out_dtype=torch.float32)
-            proj = model.mm_projector(feats, out_dtype=out_dtype) if not isinstance(model.mm_projector, GatedBlock) \
-                else torch.cat([model.mm_projector(f, out_dtype=out_dtype) for f in torch.split(feats, 1)], 0)
+            proj = model.mm_projector(feats, out_dtype=out_dtype, **T16) if not isinstance(model.mm_projector, GatedBlock) \
+                else torch.cat([model.mm_projector(f, out_dtype=out_dtype, **T16) for f in torch.split(feats, 1)], 0)
             return list(torch.split(proj, split_sizes, dim=0)), split_sizes
 
         feats = tower(images, out_dtype=torch.float32)
-        return model.mm_projector(feats, out_dtype=out_dtype), split_sizes
+        return model.mm_projector(feats, out_dtype=out_dtype, **T16), split_sizes
 
 
     # ------------------------------------------------------------------ splice (the step after the hot path)
@@ -454,12 +471,13 @@ class SlimeVisualEncoder(nn.Module, SlimeMetaForCausalLM):
         feats = tower(images, out_dtype=torch.float32)
         dev = feats.device
         g_idx, l_idx = _split_indices(split_sizes, dev)
-        glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32)
+        T16 = _adapter_operand_dtype(model, images)
+        glob = model.mm_projector(feats.index_select(0, g_idx), out_dtype=torch.float32, **T16)
         n_local = feats.shape[0] - len(split_sizes)
         if n_local == 0:
             return [(glob[i], glob.new_zeros((0, glob.shape[-1]))) for i in range(len(split_sizes))]
-        comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32)
-        loc = _project_local(model.mm_projector, comp)
+        comp = model.sampler.post_qformer(feats.index_select(0, l_idx), out_dtype=torch.float32, **T16)
+        loc = _project_local(model.mm_projector, comp, T16.get("operand_dtype"))
         g = model.sampler.grid_size
         outs, lstart = [], 0
         for i, s in enumerate(split_sizes):

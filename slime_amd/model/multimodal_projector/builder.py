@@ -63,9 +63,12 @@ class HipMlp(nn.Sequential):
         return self._packed[key]
 
     @torch.no_grad()
-    def forward(self, x, out_dtype: Optional[torch.dtype] = None):
+    def forward(self, x, out_dtype: Optional[torch.dtype] = None, operand_dtype: Optional[torch.dtype] = None):
+        """``operand_dtype`` (extension): the 16-bit MFMA operand type when ``x`` is handed over in fp32 -- ``encode_images`` passes
+        the IMAGES' 16-bit type (the type the reference's adapter computes in: its tower returns features in the input dtype,
+        clip_encoder.py:52,56); default: x's own 16-bit type, else the weights', else bf16."""
         shp = x.shape
-        pm = self.packed(_operand_dtype(x, self[0].weight))
+        pm = self.packed(operand_dtype or _operand_dtype(x, self[0].weight))
         out = ops.mlp_forward(pm, x.reshape(-1, shp[-1]))
         return out.view(*shp[:-1], -1).to(out_dtype or x.dtype)
 
@@ -118,16 +121,17 @@ class GatedBlock(nn.Module):
         return self._packed[key]
 
     @torch.no_grad()
-    def forward(self, x, text_embedding=None, attn_mask=None, out_dtype: Optional[torch.dtype] = None):
+    def forward(self, x, text_embedding=None, attn_mask=None, out_dtype: Optional[torch.dtype] = None,
+                operand_dtype: Optional[torch.dtype] = None):
         T = self.target_sequence_length
         if x.shape[0] != T and x.shape[1] != T:                  # compressed local crops: plain MLP
-            return self.projection(x, out_dtype=out_dtype)
+            return self.projection(x, out_dtype=out_dtype, operand_dtype=operand_dtype)
         squeeze = x.dim() <= 2
         if squeeze:
             x = x.unsqueeze(0)
         if x.shape[1] != T:
             raise ValueError(f"GatedBlock expects [N, {T}, D], got {tuple(x.shape)}")
-        pg = self.packed(_operand_dtype(x, self.projection[0].weight))
+        pg = self.packed(operand_dtype or _operand_dtype(x, self.projection[0].weight))
         out = ops.gated_forward(pg, x, int(self.learnable_gated)).to(out_dtype or x.dtype)
         return out.squeeze(0) if squeeze else out
 

@@ -80,8 +80,10 @@ class Resampler(nn.Module):
         return self._packed[key]
 
     @torch.no_grad()
-    def forward(self, x, tgt_size=(24, 24), text=None, attn_mask=None, out_dtype: Optional[torch.dtype] = None):
-        """x [n, T, D] (or [T, D], squeezed back like sampler.py:141-145,170) -> [n, grid^2, D] in x.dtype."""
+    def forward(self, x, tgt_size=(24, 24), text=None, attn_mask=None, out_dtype: Optional[torch.dtype] = None,
+                operand_dtype: Optional[torch.dtype] = None):
+        """x [n, T, D] (or [T, D], squeezed back like sampler.py:141-145,170) -> [n, grid^2, D] in x.dtype.  ``operand_dtype``
+        (extension): the 16-bit MFMA operand type for an fp32 ``x`` (see HipMlp.forward)."""
         squeeze = x.dim() <= 2
         if squeeze:
             x = x.unsqueeze(0)
@@ -89,6 +91,6 @@ class Resampler(nn.Module):
         side = int(math.sqrt(T))
         if side * side != T:
             raise ValueError(f"Resampler needs a square key grid, got {T} tokens")
-        out = ops.resampler_forward(self.packed(T, self.operand_dtype(x)), x)
+        out = ops.resampler_forward(self.packed(T, operand_dtype or self.operand_dtype(x)), x)
         out = out.to(out_dtype or x.dtype)
         return out.squeeze() if squeeze else out

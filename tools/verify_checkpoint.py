@@ -131,7 +131,7 @@ def hip_report(enc, px, image_size, hs_ref, ref, dtype, dev, acfg):
     out["global"] = rel_l2(tok[:P], ref["global"])
     if n_local:
         out["merged_local"] = rel_l2(tok[P:], ref["merged"])
-        comp = model.sampler.post_qformer(feats[1:], out_dtype=torch.float32)
+        comp = model.sampler.post_qformer(feats[1:], out_dtype=torch.float32, operand_dtype=dtype)
         out["compressed"] = rel_l2(comp, ref["compressed"])
     torch.cuda.synchronize()
     return {k: (round(v, 6) if isinstance(v, float) else v) for k, v in out.items()}
