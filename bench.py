@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Contract benchmark: image-crops/sec of the SliME visual hot path (ViT + projector) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5]
     N > 1 works both ways: started plainly (`python bench.py --gpus N ...`, no WORLD_SIZE in the environment) the script
     launches its own N ranks -- it re-runs itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free port>` and passes rank 0's line through --; started under torch.distributed.run
@@ -15,6 +15,7 @@ operands, inputs already resident in HBM:
     features  ->  gated global adapter (576 tokens/image), post_qformer local compression (144 tokens/crop) + MLP
     projector, spatial merge into LLM-ready token rows.
 
+--config 1  BASELINE configs[0] on the HIP path: ONE 336 x 336 crop, global view only, batch 1 (tower + GatedBlock): a latency line.
 --config 3  BASELINE configs[2]: 4 images x (1 global + 16 local) = 68 crops, STRONG scaling: the crop list is block
             partitioned over the ranks (ceil(68/N) per rank, zero-padded: slime_amd.dist.sharded_tower), features are
             all-gathered (chunked, under the tower), the adapter (4 x 4 spatial merge) runs on the image-owning rank.
@@ -62,6 +63,7 @@ PMC_FILE = next((f for f in ("r06_pmc_kernels.json", "r05_pmc_kernels.json") if 
 REPEATS = 3                            # the K-step region is timed this many times back to back; the headline is the FIRST (the driver-visible) one
 
 CONFIGS = {                            # images per step, local crops per image, local grid
+    1: dict(images=1, local=0, grid=(1, 1), scaling="weak"),     # BASELINE configs[0] on the HIP path: one 336 x 336 crop, global view only, batch 1 (a latency line)
     2: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
     3: dict(images=4, local=16, grid=(4, 4), scaling="strong"),
     4: dict(images=8, local=4, grid=(2, 2), scaling="weak"),
@@ -407,6 +409,7 @@ def pmc_traffic(rocprof_name, profiled_shape=True):
         return None, src, None, f"cannot read {src}: {e}"
     meta = table.get("_meta", {})
     head = meta.get("git_head")
+    pmc_traffic.csrc_sha = meta.get("csrc_sha")             # digest of the kernel sources the passes were taken on (None: rounds <= 5)
     rec = table.get(rocprof_name)
     if rec is None:                                       # the summary keys some kernels with their variant / grid ("prefill32_kernel<BF16, 6> [grid 65536]")
         stem = rocprof_name.rstrip(">")
@@ -463,6 +466,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.config == 4 and world > 1:
         raise SystemExit("--config 4 is the single-GPU prefill configuration (BASELINE configs[3]); the sharded one is --config 5")
+    if args.config == 1 and world > 1:
+        raise SystemExit("--config 1 is one crop on one GPU (BASELINE configs[0])")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     import torch.distributed as dist
@@ -530,7 +535,7 @@ def main():
                 # adapter -- is the strong form, timed in the same run as the `strong` object.
                 allf = torch.empty((world * feats.shape[0],) + tuple(feats.shape[1:]), dtype=feats.dtype, device=feats.device)
                 work = dist.all_gather_into_tensor(allf, feats.contiguous(), async_op=True)
-            out = ops.adapter_forward(cur["pg"], cur["post"], feats, IMAGES, LOCAL, NW, NH, True, -1, cur["dt"])
+            out = ops.adapter_forward(cur["pg"], cur["post"] if LOCAL else None, feats, IMAGES, LOCAL, NW, NH, LOCAL > 0, -1, cur["dt"])
             if collective:
                 work.wait()
             return out
@@ -705,12 +710,14 @@ def main():
         # the driver's line (config 2, 40 crops per GPU) must carry a traffic figure; other launch shapes carry one if profiled
         calib = mfma_stream_calibration(dev, dt, box)
         traffic, traffic_src, traffic_head, traffic_err = pmc_traffic(roof_kernel["rocprof_name"], profiled_shape=(args.config == 2 and not strong and world == 1))
-        workload = {2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
+        workload = {1: "CLIP-ViT-L/14-336, ONE 336x336 crop (global view only, batch 1: BASELINE configs[0] on the HIP path), tower + GatedBlock on the global view -- a latency line: 117 dependent launches on a chip they cannot fill",
+                    2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
                     3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
                     4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers",
                     5: "video path: 8 frames x (1+4) crops = 40 ViT forwards block-partitioned over the GPUs, all-gather, adapter for all frames, visual-token splice into ONE 9280-position sequence + the attention sub-layer of 32 Llama-3-8B layers (replicated per rank)"}[args.config]
         res = {
-            "metric": "image-crops/sec (ViT+projector) at 336px, 1+4 grid" if args.config != 3 else "image-crops/sec (ViT+projector) at 336px, 1+16 grid",
+            "metric": {1: "image-crops/sec (ViT+projector) at 336px, single crop (global only, batch 1)",
+                       3: "image-crops/sec (ViT+projector) at 336px, 1+16 grid"}.get(args.config, "image-crops/sec (ViT+projector) at 336px, 1+4 grid"),
             "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
             "ms_per_step_repeats": [round(r / args.steps * 1e3, 3) for r in repeats_s],
@@ -739,6 +746,8 @@ def main():
                          "kernel": f"{roof_kernel['rocprof_name']} ({roof_kernel['label']}, M={roof_kernel['M']} N={roof_kernel['N']} K={roof_kernel['K']})",
                          "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof_kernel["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head,
+                         # do the committed PMC passes describe the kernel sources this library was built from?
+                         "traffic_current": (getattr(pmc_traffic, "csrc_sha", None) == ops._lib.csrc_digest()) if getattr(pmc_traffic, "csrc_sha", None) else None,
                          **({"traffic_error": traffic_err} if traffic_err else {}),
                          "traffic_algorithmic": roof_kernel.get("algorithmic_bytes"),
                          "launch_ms": roof_kernel["ms"], "launch_ms_min": roof_kernel["min_ms"], "launch_ms_max": roof_kernel.get("max_ms"),

@@ -180,6 +180,20 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(slime_[a-z0-9_]+)\s*\(", text)))
 
 
+def csrc_digest() -> str:
+    """sha1 over the kernel sources (csrc/*.hip, *.h, *.inc, Makefile + include/slime_hip.h) in name order: identifies the BUILD a
+    profile was taken on (profiles/*_pmc_kernels.json: _meta.csrc_sha) independently of the commit that happens to hold it."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc")) +
+                   [os.path.join(CSRC, "Makefile"), HEADER_PATH])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = False) -> str:
     """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", CSRC, f"-j{max(4, min(16, os.cpu_count() or 4))}"]      # product + diagnostic library

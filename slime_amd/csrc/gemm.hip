@@ -2003,6 +2003,9 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 #ifndef SLIME_OPT_TILE64
 #define SLIME_OPT_TILE64 1
 #endif
+#ifndef SLIME_OPT_DB96
+#define SLIME_OPT_DB96 1
+#endif
 static int auto_tile(const GemmArgs& g) {
     int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
     if (tile == 4) {
@@ -2037,6 +2040,16 @@ static int auto_tile(const GemmArgs& g) {
     // (tower over 1 / 3 / 5 crops 3.12 -> 2.40 / 3.25 -> 2.75 / 3.68 -> 3.18 ms; beyond one workgroup per CU the two-stage form's second
     // resident workgroup is worth more: 9 crops 4.78 vs 5.10 -- tools/rank_shapes.py, profiles/r03_small_batch_latency_c.txt)
     if (tile == 3 && (long)((g.M + 127) / 128) * (g.N / 128) <= num_cus()) tile = 15;
+    // ... and the long-K direct-B grids of that band (fc2 at 8-10 crops) whose 96-row form still gives every workgroup a CU of its own run
+    // 96 x 256 tiles (tile 19, round 6): such a launch is bound by how many CUs hold a workgroup at all (164 of 256 at 9 crops), and 4/3
+    // as many workgroups of 3/4 the height put more of them to work: fc2 at 9 crops 70.0 -> 65.2 us, tower over 16 / 17 / 20 crops
+    // (two streams of 8-10) -2.6 / -1.7 / -1.3 %.  The rule stops where a second workgroup would land on a CU (11 crops: 268 workgroups:
+    // +4 %) and does not extend to the K = 1024 launches: q/k/v at 5-6 crops is ahead on one stream and behind by 2-5 % when two half
+    // batches co-run, out_proj at 20 crops is 10 % faster stand-alone and costs the step 0.3-0.5 % (profiles/r06_db96_first_rule_ab.txt,
+    // r06_small_tiles.txt, r06_tile_ab_attention_conflict.txt).  Same k order per accumulator, same epilogue: bit-identical.
+#if SLIME_OPT_DB96
+    if (tile == 12 && g.K > 2048 && (long)((g.M + 95) / 96) * (g.N / 256) <= (long)num_cus()) tile = 19;
+#endif
     // ... and grids that leave HALF the CUs without even a 128 x 128 workgroup (one to three crops: BASELINE config 1, the smallest rank
     // shards) run 64 x 64 tiles on the same three-stage ring (tile 18, round 5): four times the workgroups, and a wave's chain per k-tile
     // is 8 MFMAs instead of 32 -- these launches are bound by that dependent chain (fc2 at one crop: 40 workgroups x 64 k-tiles), not by
@@ -2065,6 +2078,15 @@ extern "C" void slime_gemm_set_shape_tile(int N, int K, int tile) {
     if (g_rules < 8) { g_rule_n[g_rules] = N; g_rule_k[g_rules] = K; g_rule_tile[g_rules] = tile; ++g_rules; }
 }
 #endif
+
+// epilogues the 96-row direct-B tile is built for: fc2's (the one launch the dispatch gives it); the diagnostic build adds the tower's
+// other two for the per-shape A/B tools (tools/r6_tile_ab.py, r6_small_tiles.py).  Every other epilogue keeps 128 rows.
+constexpr bool db96_epilogue(int epi) {
+#ifdef SLIME_DIAG
+    if (epi == SLIME_EPI_BIAS_T || epi == SLIME_EPI_BIAS_QUICKGELU_T) return true;
+#endif
+    return epi == SLIME_EPI_BIAS_RESID_SPLIT_LN;
+}
 
 template <typename T, int EPI>
 static int launch_epi(const GemmArgs& g, hipStream_t stream) {
@@ -2100,13 +2122,13 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
     if (tile == 18) return launch_cfg<T, 64, 64, 4, 1, EPI, 2>(g, stream);        // 64 x 64, three-stage ring (the smallest grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
-#ifdef SLIME_DIAG
-    if (tile == 19) {                                             // round 6: 96-row direct-B tiles, K <= 1024-class launches of the tower only
-        if constexpr (EPI == SLIME_EPI_BIAS_T || EPI == SLIME_EPI_BIAS_QUICKGELU_T || EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN) {
-            if (g.Bf && g.K < 2048) return launch_db_k<T, EPI, 0, 6>(g, stream);
+    if (tile == 19) {                                             // 96-row direct-B tiles: instantiated for the tower's epilogues (db96_epilogue)
+        if constexpr (db96_epilogue(EPI)) {
+            if (g.Bf) return launch_db<T, EPI, 6>(g, stream);
         }
         return launch_db<T, EPI, 8>(g, stream);
     }
+#ifdef SLIME_DIAG
     if (tile == 13) return launch_db<T, EPI, 4>(g, stream);       // measured alternative (64-row direct-B tiles), see gemm_db_kernel
 #else
     if (tile == 13) return launch_db<T, EPI, 8>(g, stream);
@@ -2143,7 +2165,8 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     const int tile = auto_tile(g);
     const char* t = dtype == SLIME_F16 ? "F16" : "BF16";
     const int ktag = K >= 2048 ? 1 : 0;
-    if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
+    if (tile == 19) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, db96_epilogue(epilogue) ? 6 : 8);
+    else if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
     else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
     else if (tile == 18) snprintf(out, out_len, "gemm_kernel<%s, 64, 64, 4, 1, %d, 2>", t, epilogue);

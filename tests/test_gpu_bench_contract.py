@@ -104,17 +104,19 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     assert res.returncode != 0 and "GPU(s)" in res.stderr and not res.stdout.strip()
 
 
-@pytest.mark.parametrize("config,extra", [(3, []), (4, []), (5, []), (3, ["--gpus", "2"])])
+@pytest.mark.parametrize("config,extra", [(1, []), (3, []), (4, []), (5, []), (3, ["--gpus", "2"])])
 def test_bench_other_configs_print_their_line(config, extra):
     """BASELINE configs 3 / 4 / 5 through bench.py, 2 steps each (and the strong-scaling ones once more as a self-launched 2-rank
     rehearsal on the one GPU): those modes are not what the driver runs, so nothing else would notice them rotting."""
     d = _bench(["--config", str(config), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, ONE_GPU_REHEARSAL if extra else None)
     world = 2 if extra else 1
     assert d["n_gpus"] == world and d["steps"] == 2 and d["config"]["baseline_config"] == config
-    assert d["scaling"] == {3: "strong", 4: "weak", 5: "strong"}[config]
-    crops = {3: 68, 4: 40, 5: 40}[config]
+    assert d["scaling"] == {1: "weak", 3: "strong", 4: "weak", 5: "strong"}[config]
+    crops = {1: 1, 3: 68, 4: 40, 5: 40}[config]
     assert abs(d["value"] - crops * 1e3 / d["ms_per_step"]) / d["value"] < 0.01      # strong scaling / one GPU: the step's crops, once
     assert d["config"]["crops_per_gpu"] == -(-crops // world) if config != 4 else d["config"]["crops_per_gpu"] == 40
+    if config == 1:                                               # one crop: the 64 x 64 ring tile is what runs (auto_tile's smallest-grid rule)
+        assert "single crop" in d["metric"] and "gemm_kernel<BF16, 64, 64" in d["roofline"]["kernel"] and d["ms_per_step"] < 5.0
     r = d["roofline"]
     assert 0.02 < r["frac"] < 1.0 and r["achieved"] > 0 and "traffic_error" not in r
     if config in (4, 5):

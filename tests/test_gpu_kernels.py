@@ -195,12 +195,13 @@ def test_gemm_direct_b_production_shapes(dev, dtype, M, N, K):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(1731, 1024, 1024), (300, 768, 640), (77, 256, 64), (2308, 512, 128), (128, 256, 192), (129, 256, 128),
                                    (11540, 1024, 4096), (2885, 1024, 4096)])
-@pytest.mark.parametrize("tile", [12, 13])
+@pytest.mark.parametrize("tile", [12, 13, 19])
 def test_gemm_direct_b_small_and_edge_shapes(dev, dtype, M, N, K, tile):
     """The same kernel forced (diagnostic build) onto shapes the dispatch would not give it: one k-tile (K = 64: prologue +
     last-tile body only), two and three k-tiles (every tile-body variant), M < 128, M = 128 exactly, one row over, and the
     sub-round K = 4096 grids (fc2 at a 20-crop and a 5-crop batch) that the auto rule leaves to the LDS-staged kernels.
-    tile 12 = 128-row, 13 = 64-row workgroup tiles."""
+    tile 12 = 128-row, 13 = 64-row, 19 = 96-row (round 6) workgroup tiles; M = 77 / 128 / 129 / 300 also walk the 96-row tile's ragged
+    last row tile (the forced tile takes the 96-row form for the tower's epilogues, the 128-row one for the others)."""
     from slime_amd import _lib
     with _lib.diag() as lib:
         lib.slime_gemm_force_tile(tile)
@@ -492,7 +493,8 @@ def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K,tile", [(11540, 1024, 4096, 0), (11540, 1024, 1024, 0), (2885, 1024, 4096, 0), (577, 1024, 1024, 0),
                                         (1731, 1024, 1024, 4), (300, 768, 640, 3), (2308, 512, 128, 15), (1731, 1024, 1024, 12),
-                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 1), (1731, 1024, 1024, 18), (577, 1024, 4096, 18)])
+                                        (1731, 1024, 1024, 11), (1731, 1024, 1024, 1), (1731, 1024, 1024, 18), (577, 1024, 4096, 18),
+                                        (1731, 1024, 1024, 19), (5193, 1024, 4096, 19), (11540, 1024, 1024, 19), (100, 1024, 1024, 19)])
 def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
     """SLIME_EPI_BIAS_RESID_SPLIT_LN (round 5): the residual update on a 2 x 16-bit split stream.  Against fp32 torch on the same
     operands: hi' = T(c) EXACTLY for c = the kernel's own fp32 result (checked through the fp32 epilogue, which computes the same c
@@ -575,6 +577,34 @@ def test_gemm_from_fragment_image_alone(dev, dtype, M, N, K, tile):
                       epilogue=_lib.EPI_BIAS_F32)
     import ctypes
     assert _lib.load().slime_gemm_ex(ctypes.byref(g), 0) == -1 and b"null pointer" in _lib.load().slime_last_error()     # C ABI: B and B_frag both NULL
+
+
+def test_sub_round_long_k_direct_b_grids_use_96_row_tiles(dev):
+    """auto_tile (round 6): fc2's direct-B launches whose 96-row grid still gives every workgroup a CU of its own (8-10 crops) take the
+    96 x 256 tile; 11 crops on (a second workgroup on some CU), the K = 1024 launches and epilogues it is not built for keep 128 rows.
+    The tile is bit-invisible: the split-residual update of 9 crops' rows (96-row tiles) equals the same rows inside a 12-crop launch
+    (128-row tiles) -- both planes and the LayerNorm partial sums."""
+    from slime_amd import ops, _lib
+    dt = torch.bfloat16
+    name = lambda M, N, K, epi: ops.gemm_kernel_name(M, N, K, dt, epi, True)
+    split = _lib.EPI_BIAS_RESID_SPLIT_LN
+    for crops, mi in ((8, 6), (9, 6), (10, 6), (11, 8), (12, 8), (13, 8)):
+        assert name(577 * crops, 1024, 4096, split) == f"gemm_db_kernel<BF16, 8, 1, {mi}>", crops
+    assert name(2885, 3072, 1024, _lib.EPI_BIAS_T).endswith(", 8>") and name(11540, 1024, 1024, split).endswith(", 8>")     # K = 1024: 128 rows
+    assert "gemm_pp_kernel" in name(11540, 1024, 4096, split)                                   # the 20-crop half batch stays on the ping-pong kernel
+    M9, M12 = 9 * 577, 12 * 577
+    a2 = _rand((M12, 4096), dt, dev, 4)
+    w2 = _rand((1024, 4096), dt, dev, 5, 1 / 64)
+    b2 = _rand((1024,), torch.float32, dev, 6)
+    wf2 = ops.pack_b_frag(w2)
+    h0 = _rand((M12, 1024), torch.float32, dev, 7, 2.0)
+    hi0 = h0.to(dt)
+    lo0 = (h0 - hi0.float()).to(dt)
+    hi_a, lo_a = hi0.clone(), lo0.clone()
+    st_a = ops.gemm_resid_split(a2, None, b2, hi_a, lo_a, w_frag=wf2)
+    hi_b, lo_b = hi0[:M9].clone(), lo0[:M9].clone()
+    st_b = ops.gemm_resid_split(a2[:M9].contiguous(), None, b2, hi_b, lo_b, w_frag=wf2)
+    assert torch.equal(hi_a[:M9], hi_b) and torch.equal(lo_a[:M9], lo_b) and torch.equal(st_a[:M9], st_b)
 
 
 def test_small_grid_dispatch_uses_64_row_tiles(dev):

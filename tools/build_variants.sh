@@ -12,7 +12,7 @@ for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}
   d=build_var_$name; mkdir -p $d
   ( objs=""
-    for f in gemm attention prefill rowwise router slicer patch_embed api; do
+    for f in gemm attention prefill rowwise router slicer patch_embed calib api; do
       if [[ " ${FILES:-gemm attention} " == *" $f "* ]]; then
         extra=""; [[ $f == attention || $f == prefill ]] && extra="-fno-honor-nans"
         /opt/rocm/bin/hipcc $FLAGS $defs $extra -c $f.hip -o $d/$f.o || exit 1

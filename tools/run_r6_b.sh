@@ -12,3 +12,5 @@ for n in 5 9; do
 done
 cd "$R"; rm -rf gpurun_out/prof_*
 cat gpurun_out/r6_b_tile_ab.txt; cat gpurun_out/r6_b_gap5.txt gpurun_out/r6_b_gap9.txt; head -8 gpurun_out/r6_b_gap5_kernel_stats.csv | cut -c1-160
+( timeout 600 python -m pytest "tests/test_gpu_modules.py::test_encode_images_vs_oracle" "tests/test_gpu_modules.py::test_config1_plugin_api_one_crop_full_size" "tests/test_gpu_modules.py::test_encode_images_flags_and_mask" tests/test_checkpoints.py -m gpu -q -rf -s 2>&1 | grep -v "^$" | tail -40 ) > gpurun_out/r6_b_retests.txt
+tail -12 gpurun_out/r6_b_retests.txt

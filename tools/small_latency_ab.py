@@ -4,7 +4,7 @@ process per library (SLIME_HIP_LIBRARY), rounds interleaved; prints ms per pass 
 choice must be bit-invisible).  usage: small_latency_ab.py [--rounds R] name ...   (name 'product' = slime_amd/libslime_hip.so)"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIZES = (1, 2, 3, 4, 5, 7, 9, 12)
+SIZES = tuple(int(x) for x in os.environ["AB_SIZES"].split(",")) if os.environ.get("AB_SIZES") else (1, 2, 3, 4, 5, 7, 9, 12)   # AB_SIZES=4,5,6,...: other crop counts
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import time, hashlib, torch
     sys.path.insert(0, ROOT)
@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
     dev, dt = torch.device("cuda:0"), torch.bfloat16
     vm = HipCLIPVisionModel(W.CLIP_L_336); vm.load_state_dict(W.make_tower_state_dict(W.CLIP_L_336, seed=1234)); vm.to(dev).to(dt)
-    px = W.synthetic_pixels(12, seed=0).to(dev).to(dt)
+    px = W.synthetic_pixels(max(12, max(SIZES)), seed=0).to(dev).to(dt)
     out = {}
     for n in SIZES:
         x = px[:n].contiguous()
@@ -23,7 +23,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             for _ in range(10): vm.encode(x)
             torch.cuda.synchronize(); best.append((time.perf_counter() - t0) / 10 * 1e3)
         out[n] = round(min(best), 3)
-    f = vm.encode(px); torch.cuda.synchronize()
+    f = vm.encode(px[:12].contiguous()); torch.cuda.synchronize()
     print(json.dumps({"ms": out, "sha": hashlib.sha1(f.float().cpu().numpy().tobytes()).hexdigest()[:12]}))
     sys.exit(0)
 args = sys.argv[1:]; rounds = 2

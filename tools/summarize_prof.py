@@ -43,7 +43,12 @@ def main():
     os.makedirs("profiles", exist_ok=True)
     # which build the passes ran on (the GPU box has no .git: the run script hands the commit over in SLIME_GIT_HEAD); bench.py prints
     # it as roofline.traffic_head next to the traffic figure it reads from this file
-    out["_meta"] = {"git_head": os.environ.get("SLIME_GIT_HEAD", "unknown"), "target": "tools/pmc_target.py",
+    # ... and a digest of the kernel sources the profiled library was built from (slime_amd/csrc): bench.py recomputes it and says in
+    # `roofline.traffic_current` whether the committed passes describe the build that is running (the r05 figure predated
+    # later staging changes and only the commit stamp said so)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from slime_amd._lib import csrc_digest
+    out["_meta"] = {"git_head": os.environ.get("SLIME_GIT_HEAD", "unknown"), "csrc_sha": csrc_digest(), "target": "tools/pmc_target.py",
                     "passes": ["prof_pmc_sq", "prof_pmc_fetch", "prof_pmc_write"]}
     json.dump(out, open(f"profiles/{tag}_pmc_kernels.json", "w"), indent=1, sort_keys=True)
     del out["_meta"]
