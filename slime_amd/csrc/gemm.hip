@@ -2003,8 +2003,11 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
 #ifndef SLIME_OPT_TILE64
 #define SLIME_OPT_TILE64 1
 #endif
+#ifndef SLIME_OPT_PP192
+#define SLIME_OPT_PP192 0
+#endif
 #ifndef SLIME_OPT_DB96
-#define SLIME_OPT_DB96 1
+#define SLIME_OPT_DB96 0      // measured alternative (round 6): see auto_tile -- below the 1 % kill rule on the second lease, compiled out
 #endif
 static int auto_tile(const GemmArgs& g) {
     int tile = (g.N % 256 == 0 && g.M >= 512) ? 4 : 3;               // ping-pong 256x256, else 128x128
@@ -2030,6 +2033,11 @@ static int auto_tile(const GemmArgs& g) {
         // wins everywhere but on sub-round K = 4096 grids (fc2 at 11540 rows: 184 tiles, 0.96-1.0x), most at small batches
         // (2885 rows: fc1 669 -> 857, qkv 564 -> 649 TF/s); the two-stream tower is 2.5-3 % faster with qkv / out_proj / fc1 on it.
         if (tile != 3 && g.Bf && (n256 >= cus || g.K <= 2048)) tile = 12;
+#if SLIME_OPT_PP192
+        // measured alternative (round 6 re-measurement of the rule's first paragraph with today's kernels): sub-round ping-pong grids
+        // (fc2 at the 20-crop half batch: 184 tiles) on 192-row tiles (244 tiles = 0.95 of a round)
+        if (tile == 4 && n256 < cus && n192 <= cus) tile = 9;
+#endif
     }
     // ... and K > 2048 grids (fc2) in the band where the rule above falls back to the two-stage 128 x 128 kernel although its grid
     // exceeds one workgroup per CU (half batches of 8-12 crops): the direct-B kernel's two-k-step fragment flight covers an under-
@@ -2040,13 +2048,16 @@ static int auto_tile(const GemmArgs& g) {
     // (tower over 1 / 3 / 5 crops 3.12 -> 2.40 / 3.25 -> 2.75 / 3.68 -> 3.18 ms; beyond one workgroup per CU the two-stage form's second
     // resident workgroup is worth more: 9 crops 4.78 vs 5.10 -- tools/rank_shapes.py, profiles/r03_small_batch_latency_c.txt)
     if (tile == 3 && (long)((g.M + 127) / 128) * (g.N / 128) <= num_cus()) tile = 15;
-    // ... and the long-K direct-B grids of that band (fc2 at 8-10 crops) whose 96-row form still gives every workgroup a CU of its own run
-    // 96 x 256 tiles (tile 19, round 6): such a launch is bound by how many CUs hold a workgroup at all (164 of 256 at 9 crops), and 4/3
-    // as many workgroups of 3/4 the height put more of them to work: fc2 at 9 crops 70.0 -> 65.2 us, tower over 16 / 17 / 20 crops
-    // (two streams of 8-10) -2.6 / -1.7 / -1.3 %.  The rule stops where a second workgroup would land on a CU (11 crops: 268 workgroups:
-    // +4 %) and does not extend to the K = 1024 launches: q/k/v at 5-6 crops is ahead on one stream and behind by 2-5 % when two half
-    // batches co-run, out_proj at 20 crops is 10 % faster stand-alone and costs the step 0.3-0.5 % (profiles/r06_db96_first_rule_ab.txt,
-    // r06_small_tiles.txt, r06_tile_ab_attention_conflict.txt).  Same k order per accumulator, same epilogue: bit-identical.
+    // Measured alternative, OFF (round 6, VERDICT r5 item 4: a row-tile height that fills the round): 96 x 256 direct-B tiles (tile 19,
+    // gemm_db_kernel<.., 6>; bit-identical: same k order per accumulator, same epilogue).  Stand-alone the quantisation argument holds
+    // for the sub-round launches -- out_proj at 20 crops 43.7 -> 39.8 us (364 -> 484 workgroups in 512 slots), fc2 at 9 crops 70.0 -> 65.2,
+    // q/k/v at 5 crops 30.5 -> 27.1 -- and fails for the multi-round ones (q/k/v, fc1 at 20 crops: +3 / +6 %: the per-workgroup prologue /
+    // epilogue of the extra tiles costs more than the round returns).  Inside the product's stream policy it buys nothing robust: as a
+    // rule for every direct-B grid that fits one round of slots it is ahead on one stream and 2-5 % BEHIND when two half batches co-run
+    // (10 / 12 / 21 / 24 crops), and out_proj on it costs the bench step 0.3-0.5 %; narrowed to fc2 at 8-10 crops per stream (96-row grid
+    // <= one workgroup per CU) it measured -2.6 / -1.7 / -1.3 % at 16 / 17 / 20 crops on one lease and -0.75 / -1.3 / -0.3 % (+1.7 % at
+    // 21) on the next -- below the 1 % kill rule.  profiles/r06_tile_ab_attention_conflict.txt, r06_small_tiles.txt,
+    // r06_db96_first_rule_ab.txt, r06_db96_narrow_rule_ab.txt.
 #if SLIME_OPT_DB96
     if (tile == 12 && g.K > 2048 && (long)((g.M + 95) / 96) * (g.N / 256) <= (long)num_cus()) tile = 19;
 #endif
@@ -2106,7 +2117,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     if (tile == 5 && g.K < 128) tile = 4;                              // persistent kernel needs >= 2 k-tiles
     if (tile == 5 && ((size_t)g.M * g.lda * 2 >= (1ull << 32) || (size_t)g.N * g.K * 2 >= (1ull << 32))) tile = 4;   // 32-bit row offsets
     if (tile == 5) return launch_ppp<T, EPI>(g, stream);
+#if !SLIME_OPT_PP192
     if (tile == 9) return launch_pp192<T, EPI>(g, stream);
+#endif
     if (tile == 1) return g_sched == 0 ? launch_cfg<T, 256, 256, 2, 4, EPI, 0>(g, stream) : launch_cfg<T, 256, 256, 2, 4, EPI, 1>(g, stream);
     if (tile == 3 && g_sched == 0) return launch_cfg<T, 128, 128, 2, 2, EPI, 0>(g, stream);
 #endif
@@ -2119,6 +2132,9 @@ static int launch_epi(const GemmArgs& g, hipStream_t stream) {
     // B = NULL (the caller holds the fragment-order image only): the lock-step, ping-pong and direct-B kernels read it; the stream
     // kernel (never picked by auto_tile when a fragment image exists) is replaced by the direct-B kernel, or the ping-pong one
     if (!g.B && (tile == 10 || tile == 11)) tile = g.Bf ? 12 : 4;
+#if SLIME_OPT_PP192
+    if (tile == 9) return launch_pp192<T, EPI>(g, stream);
+#endif
     if (tile == 15) return launch_cfg<T, 128, 128, 2, 2, EPI, 2>(g, stream);      // 128 x 128, three-stage ring (small grids)
     if (tile == 18) return launch_cfg<T, 64, 64, 4, 1, EPI, 2>(g, stream);        // 64 x 64, three-stage ring (the smallest grids)
     if (tile == 12) return launch_db<T, EPI, 8>(g, stream);
@@ -2167,7 +2183,7 @@ extern "C" int slime_gemm_kernel_name(int M, int N, int K, int dtype, int epilog
     const int ktag = K >= 2048 ? 1 : 0;
     if (tile == 19) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, db96_epilogue(epilogue) ? 6 : 8);
     else if (tile == 12 || tile == 13) snprintf(out, out_len, "gemm_db_kernel<%s, %d, %d, %d>", t, epilogue, ktag, tile == 12 ? 8 : 4);
-    else if (tile == 4) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, 4>", t, epilogue, ktag);
+    else if (tile == 4 || tile == 9) snprintf(out, out_len, "gemm_pp_kernel<%s, %d, %d, 0, %d>", t, epilogue, ktag, tile == 4 ? 4 : 3);
     else if (tile == 10 || tile == 11) snprintf(out, out_len, "gemm_w4_kernel<%s, %d, %d, %d, 0>", t, epilogue, ktag, tile == 10 ? 6 : 8);
     else if (tile == 18) snprintf(out, out_len, "gemm_kernel<%s, 64, 64, 4, 1, %d, 2>", t, epilogue);
     else snprintf(out, out_len, "gemm_kernel<%s, 128, 128, 2, 2, %d, %d>", t, epilogue, tile == 15 ? 2 : 1);

@@ -579,19 +579,19 @@ def test_gemm_from_fragment_image_alone(dev, dtype, M, N, K, tile):
     assert _lib.load().slime_gemm_ex(ctypes.byref(g), 0) == -1 and b"null pointer" in _lib.load().slime_last_error()     # C ABI: B and B_frag both NULL
 
 
-def test_sub_round_long_k_direct_b_grids_use_96_row_tiles(dev):
-    """auto_tile (round 6): fc2's direct-B launches whose 96-row grid still gives every workgroup a CU of its own (8-10 crops) take the
-    96 x 256 tile; 11 crops on (a second workgroup on some CU), the K = 1024 launches and epilogues it is not built for keep 128 rows.
-    The tile is bit-invisible: the split-residual update of 9 crops' rows (96-row tiles) equals the same rows inside a 12-crop launch
-    (128-row tiles) -- both planes and the LayerNorm partial sums."""
+def test_96_row_direct_b_tile_is_a_bit_identical_alternative(dev):
+    """Round 6: the 96 x 256 direct-B tile (diagnostic tile 19) was measured and NOT adopted (profiles/r06_db96_*_ab.txt): the product
+    dispatch keeps 128-row tiles at every shape the rule had fired on; forced, the tile is bit-invisible -- the split-residual update
+    of 9 crops' rows on 96-row tiles equals the same rows of a 12-crop launch on 128-row tiles (both planes + LayerNorm partial sums),
+    and a LayerNorm-fold consumer launch (q/k/v shape) equals the product's."""
     from slime_amd import ops, _lib
     dt = torch.bfloat16
     name = lambda M, N, K, epi: ops.gemm_kernel_name(M, N, K, dt, epi, True)
     split = _lib.EPI_BIAS_RESID_SPLIT_LN
-    for crops, mi in ((8, 6), (9, 6), (10, 6), (11, 8), (12, 8), (13, 8)):
-        assert name(577 * crops, 1024, 4096, split) == f"gemm_db_kernel<BF16, 8, 1, {mi}>", crops
-    assert name(2885, 3072, 1024, _lib.EPI_BIAS_T).endswith(", 8>") and name(11540, 1024, 1024, split).endswith(", 8>")     # K = 1024: 128 rows
-    assert "gemm_pp_kernel" in name(11540, 1024, 4096, split)                                   # the 20-crop half batch stays on the ping-pong kernel
+    for crops in (8, 9, 10, 11, 12, 13):
+        assert name(577 * crops, 1024, 4096, split) == "gemm_db_kernel<BF16, 8, 1, 8>", crops
+    assert name(2885, 3072, 1024, _lib.EPI_BIAS_T).endswith(", 8>") and name(11540, 1024, 1024, split).endswith(", 8>")
+    assert "gemm_pp_kernel" in name(11540, 1024, 4096, split)
     M9, M12 = 9 * 577, 12 * 577
     a2 = _rand((M12, 4096), dt, dev, 4)
     w2 = _rand((1024, 4096), dt, dev, 5, 1 / 64)
@@ -601,10 +601,22 @@ def test_sub_round_long_k_direct_b_grids_use_96_row_tiles(dev):
     hi0 = h0.to(dt)
     lo0 = (h0 - hi0.float()).to(dt)
     hi_a, lo_a = hi0.clone(), lo0.clone()
-    st_a = ops.gemm_resid_split(a2, None, b2, hi_a, lo_a, w_frag=wf2)
-    hi_b, lo_b = hi0[:M9].clone(), lo0[:M9].clone()
-    st_b = ops.gemm_resid_split(a2[:M9].contiguous(), None, b2, hi_b, lo_b, w_frag=wf2)
+    st_a = ops.gemm_resid_split(a2, None, b2, hi_a, lo_a, w_frag=wf2)                      # product dispatch: 128-row tiles
+    a3 = _rand((5 * 577, 1024), dt, dev, 8)
+    w3 = _rand((3072, 1024), dt, dev, 9, 1 / 32)
+    b3 = _rand((3072,), torch.float32, dev, 10)
+    wf3 = ops.pack_b_frag(w3)
+    want3 = ops.gemm(a3, None, b3, _lib.EPI_BIAS_T, w_frag=wf3)
+    with _lib.diag() as lib:
+        lib.slime_gemm_force_tile(19)
+        try:
+            hi_b, lo_b = hi0[:M9].clone(), lo0[:M9].clone()
+            st_b = ops.gemm_resid_split(a2[:M9].contiguous(), None, b2, hi_b, lo_b, w_frag=wf2)
+            got3 = ops.gemm(a3, None, b3, _lib.EPI_BIAS_T, w_frag=wf3)
+        finally:
+            lib.slime_gemm_force_tile(0)
     assert torch.equal(hi_a[:M9], hi_b) and torch.equal(lo_a[:M9], lo_b) and torch.equal(st_a[:M9], st_b)
+    assert torch.equal(got3, want3)
 
 
 def test_small_grid_dispatch_uses_64_row_tiles(dev):
