@@ -394,6 +394,17 @@ def parity_vs_oracle(tower_sd, adapter_sd, px, ref, dev, nw, nh):
     return out
 
 
+def pmc_profile_is_current():
+    """Do the committed PMC passes describe the kernel sources the running library was built from?  True / False by the digest
+    tools/summarize_prof.py stamped into the summary (slime_amd._lib.csrc_digest); None for a summary without one (rounds <= 5)."""
+    from slime_amd import _lib
+    try:
+        sha = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE))).get("_meta", {}).get("csrc_sha")
+    except (OSError, ValueError):
+        return None
+    return None if not sha else sha == _lib.csrc_digest()
+
+
 def pmc_traffic(rocprof_name, profiled_shape=True):
     """HBM bytes per launch of a kernel from the COMMITTED PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, profiles/README.md).
     It is a profile of this kernel at this shape, not a measurement of this run (PMC counters need rocprofv3 around the process):
@@ -409,7 +420,6 @@ def pmc_traffic(rocprof_name, profiled_shape=True):
         return None, src, None, f"cannot read {src}: {e}"
     meta = table.get("_meta", {})
     head = meta.get("git_head")
-    pmc_traffic.csrc_sha = meta.get("csrc_sha")             # digest of the kernel sources the passes were taken on (None: rounds <= 5)
     rec = table.get(rocprof_name)
     if rec is None:                                       # the summary keys some kernels with their variant / grid ("prefill32_kernel<BF16, 6> [grid 65536]")
         stem = rocprof_name.rstrip(">")
@@ -672,21 +682,27 @@ def main():
     # The default N > 1 line is weak scaling (40 crops per GPU).  north_star's data flow -- the batch's crops sharded over the GPUs,
     # an RCCL all-gather reassembling the features BEFORE the adapter -- is the strong form: timed here, in the same process group and
     # the same run, on the same 40 crops for every N, so that one driver command returns both curves.
-    strong_obj = None
-    if collective and args.config == 2 and not strong:
+    def time_strong():
         s_pixels, s_produce, s_tail, s_cfg = strong_step_fns(args.gather)
         s_elapsed, s_every = max_over_ranks(timed_region(make_step(s_produce, s_tail), phase="strong"))
         pred_n, pred_1 = D.predicted_step_ms(n_step, CPI, world), D.predicted_step_ms(n_step, CPI, 1)
-        strong_obj = {"what": "the SAME 8 x (1+4) = 40 crops block-partitioned over the ranks (slime_amd.dist.sharded_tower), all-gather of the bf16 tower "
-                              "features BEFORE the adapter, adapter on the image-owning rank; same process group, same run, W warm-up + K timed steps, max over ranks",
-                      "scaling": "strong", "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "value": round(n_step * args.steps / s_elapsed, 1),
-                      "unit": "crops/s (whole job)", "ms_per_step_rank_min": round(min(s_every) / args.steps * 1e3, 3),
-                      "ms_per_step_rank_max": round(max(s_every) / args.steps * 1e3, 3),
-                      "predicted_ms_per_step": round(pred_n, 2), "predicted_ms_per_step_n1": round(pred_1, 2),
-                      "speedup_vs_n1_predicted": round(pred_1 / pred_n, 2),
-                      "prediction": "slime_amd.dist.predicted_step_ms: tower latency profile at ceil(40 / N) crops + all-gather transfer model + adapter for the rank's images (DESIGN section 7)",
-                      **s_cfg}
-        del s_pixels
+        return {"what": "the SAME 8 x (1+4) = 40 crops block-partitioned over the ranks (slime_amd.dist.sharded_tower), all-gather of the bf16 tower "
+                        "features BEFORE the adapter, adapter on the image-owning rank; same process group, same run, W warm-up + K timed steps, max over ranks",
+                "scaling": "strong", "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "value": round(n_step * args.steps / s_elapsed, 1),
+                "unit": "crops/s (whole job)", "ms_per_step_rank_min": round(min(s_every) / args.steps * 1e3, 3),
+                "ms_per_step_rank_max": round(max(s_every) / args.steps * 1e3, 3),
+                "predicted_ms_per_step": round(pred_n, 2), "predicted_ms_per_step_n1": round(pred_1, 2),
+                "speedup_vs_n1_predicted": round(pred_1 / pred_n, 2),
+                "prediction": "slime_amd.dist.predicted_step_ms: tower latency profile at ceil(40 / N) crops + all-gather transfer model + adapter for the rank's "
+                              "images (DESIGN section 7)",
+                **s_cfg}
+
+    strong_obj = None
+    if collective and args.config == 2 and not strong:
+        try:
+            strong_obj = time_strong()
+        except Exception as e:                               # the headline line is printed whatever happens to the second curve
+            strong_obj = {"error": f"{type(e).__name__}: {e}"[:400]}
 
     if rank == 0:
         crops_total = n_step * (1 if strong else world) * args.steps
@@ -747,7 +763,7 @@ def main():
                          "achieved": roof_kernel["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(roof_kernel["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "traffic_head": traffic_head,
                          # do the committed PMC passes describe the kernel sources this library was built from?
-                         "traffic_current": (getattr(pmc_traffic, "csrc_sha", None) == ops._lib.csrc_digest()) if getattr(pmc_traffic, "csrc_sha", None) else None,
+                         "traffic_current": pmc_profile_is_current(),
                          **({"traffic_error": traffic_err} if traffic_err else {}),
                          "traffic_algorithmic": roof_kernel.get("algorithmic_bytes"),
                          "launch_ms": roof_kernel["ms"], "launch_ms_min": roof_kernel["min_ms"], "launch_ms_max": roof_kernel.get("max_ms"),
