@@ -185,6 +185,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
         return;
     }
     if constexpr (EPI == SLIME_EPI_BIAS_RESID_F32 || EPI == SLIME_EPI_BIAS_RESID_F32_LN) {
+        static_assert(EPI != SLIME_EPI_BIAS_RESID_F32_LN || NP % 2 == 0, "BIAS_RESID_F32_LN: partial sums per whole 64-column group of a wave");
         constexpr int BATCH = (MI >= 2) ? 2 : 1;          // 16-row steps per residual batch
         constexpr int NB = MI / BATCH;
         f32x4 hb[2][BATCH][NP][2];
@@ -263,6 +264,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
         // instead of 10 (4 in, 4 + 2 out); what is kept of c are 16 (bf16) / 22 (fp16) significant bits instead of 24.
         // C (= hi) and lo are read and written in place and vmcnt counts stores: both planes are fetched one 16-row step ahead
         // (one step, not two as the fp32 epilogue: two planes' addresses + unpacked halves must fit the direct-B kernel's 128 VGPRs).
+        static_assert(NP % 2 == 0, "BIAS_RESID_SPLIT_LN: a wave must own whole 64-column groups (the stores sit in the per-group loop: a 32-column "
+                                   "wave tile would store nothing -- round 6, profiles/r06_ring8_tiles.txt)");
         u32x4 rb[2][NP][2];
         char* Hi = reinterpret_cast<char*>(g.C);
         char* Lo = g.lo;
