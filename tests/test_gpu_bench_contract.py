@@ -31,10 +31,10 @@ def test_bench_prints_one_contract_line():
     # the fp16 instantiation (the reference's inference dtype, the one that meets the 1e-3 accuracy target) is timed in the same
     # run over the same region and runs at the bf16 line's speed.  Measured: fp16 is 2.3 % SLOWER than bf16 -- the
     # step is power-capped and 11-bit significands switch more multiplier bits than 8-bit ones (profiles/r04_power_cap.txt) -- so the
-    # bound is loose (8 %): the measured 3-3.5 % on an 8-step timing must not flake
+    # bound is loose (12 %): the measured 3-6 % on an 8-step timing must not flake
     f = d["fp16"]
     assert f["unit"] == "crops/s" and abs(f["value"] - 40 * 1e3 / f["ms_per_step"]) / f["value"] < 0.01
-    assert abs(f["value"] / d["value"] - 1.0) < 0.08, (f["value"], d["value"])      # round 5: 0.966-0.971 of bf16 on three leases
+    assert abs(f["value"] / d["value"] - 1.0) < 0.12, (f["value"], d["value"])      # rounds 5-6: 0.942-0.971 of bf16 over six leases (the fp16 leg runs last, on a hot chip)
     assert max(d["parity"]["fp16"]["rel_l2_global"], d["parity"]["fp16"]["rel_l2_local"]) <= 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "crops/s" and c["cores"] >= 1 and 0 < c["value"] < d["value"]
