@@ -84,7 +84,8 @@ def _adapter_operand_dtype(model, images: torch.Tensor) -> dict:
     if images.dtype not in (torch.bfloat16, torch.float16):
         return {}
     from .multimodal_resampler.sampler import Resampler
-    return {"operand_dtype": images.dtype} if isinstance(model.mm_projector, (GatedBlock, HipMlp, Resampler)) else {}
+    from .multimodal_projector.builder import HipLinear
+    return {"operand_dtype": images.dtype} if isinstance(model.mm_projector, (GatedBlock, HipMlp, HipLinear, Resampler)) else {}
 
 
 def _require_inference(model) -> None:

@@ -77,13 +77,14 @@ class HipLinear(nn.Linear):
     """``mm_projector_type='linear'``: one GEMM with bias."""
 
     @torch.no_grad()
-    def forward(self, x):
+    def forward(self, x, out_dtype: Optional[torch.dtype] = None, operand_dtype: Optional[torch.dtype] = None):
+        """``out_dtype`` / ``operand_dtype``: the extensions encode_images passes to every projector type (see HipMlp.forward)."""
         from ... import _lib
-        dt = _operand_dtype(x, self.weight)
+        dt = operand_dtype or _operand_dtype(x, self.weight)
         shp = x.shape
         a = x.reshape(-1, shp[-1]).to(dt).contiguous()
         out = ops.gemm(a, self.weight.to(dt).contiguous(), self.bias.float().contiguous(), _lib.EPI_BIAS_F32)
-        return out.view(*shp[:-1], -1).to(x.dtype)
+        return out.view(*shp[:-1], -1).to(out_dtype or x.dtype)
 
 
 class GatedBlock(nn.Module):

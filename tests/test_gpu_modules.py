@@ -498,3 +498,33 @@ def test_config1_plugin_api_one_crop_full_size(dev, dtype):
     err = rel_l2(out[0].float().cpu(), ref_g)
     print(f"config 1 through the plugin API, {dtype}: tower {rel_l2(feats.float().cpu(), ref_t):.3e} projector {err:.3e}")
     assert err <= {torch.float16: 1e-3, torch.bfloat16: 1.2e-2}[dtype], err
+
+
+@pytest.mark.parametrize("ptype", ["linear", "mlp2x_gelu"])
+def test_encode_images_plain_branch_with_other_projector_types(dev, ptype):
+    """llava_arch.py:261-267 with ``mm_projector_type`` 'linear' / 'mlp2x_gelu' and no sampler: encode_images hands every projector
+    type its fp32 tower features plus the images' 16-bit operand type (round 6: the 'linear' projector did not take the keywords
+    the branch passes).  Against torch on the tower's own features."""
+    import torch.nn.functional as F
+    from slime_amd import weights as W
+    from slime_amd.model.llava_arch import SlimeVisualEncoder, default_slime_config
+    from slime_amd.model.multimodal_encoder.clip_encoder import HipCLIPVisionModel
+    from slime_amd.image_processor import ClipImageProcessor
+    dtype = torch.float16
+    torch.manual_seed(3)
+    enc = SlimeVisualEncoder(default_slime_config("synthetic:1", hidden_size=256, mm_hidden_size=128, mm_projector_type=ptype, mm_resampler_type=None))
+    vt = enc.get_vision_tower()
+    vt.vision_tower, vt.image_processor, vt.is_loaded = HipCLIPVisionModel(W.TINY), ClipImageProcessor(), True
+    enc.load_visual_state(W.make_tower_state_dict(W.TINY, seed=11), None)          # the projector keeps its nn.Linear initialisation
+    enc.to(dev)
+    vt.vision_tower.to(dtype)
+    px = W.synthetic_pixels(2, seed=8).to(dev).to(dtype)
+    out, ss = enc.encode_images(px)
+    assert ss is None and out.shape == (2, 576, 256) and out.dtype == dtype
+    feats = enc.get_vision_tower()(px, out_dtype=torch.float32)
+    p = enc.get_model().mm_projector
+    if ptype == "linear":
+        ref = F.linear(feats, p.weight.float(), p.bias.float())
+    else:
+        ref = F.linear(F.gelu(F.linear(feats, p[0].weight.float(), p[0].bias.float())), p[2].weight.float(), p[2].bias.float())
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 2e-3
