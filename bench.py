@@ -433,6 +433,46 @@ def pmc_traffic(rocprof_name, profiled_shape=True):
     return int(rec["hbm_read_bytes_corrected"] + rec["hbm_write_bytes"]), src, head, None
 
 
+WORKLOADS = {1: "CLIP-ViT-L/14-336, ONE 336x336 crop (global view only, batch 1: BASELINE configs[0] on the HIP path), tower + GatedBlock on the global view -- a latency line: 117 dependent launches on a chip they cannot fill",
+            2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
+            3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
+            4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers",
+            5: "video path: 8 frames x (1+4) crops = 40 ViT forwards block-partitioned over the GPUs, all-gather, adapter for all frames, visual-token splice into ONE 9280-position sequence + the attention sub-layer of 32 Llama-3-8B layers (replicated per rank)"}
+
+
+class DeadlineGuard:
+    """A hang in the SECOND curve must not cost the first.  The `strong` leg of the default N > 1 line (block-partitioned crops,
+    chunked asynchronous all-gathers) has only ever run as a 2-rank rehearsal on one GPU -- no multi-GPU box was available in six
+    rounds -- and it runs BEFORE rank 0 prints, because the contract is ONE JSON line.  Every rank arms this timer around the leg;
+    if the leg has not returned after `seconds` the timer thread of rank 0 prints the headline it already holds (timed, max over
+    ranks, complete) with `strong: {"error": "timeout ..."}` and no probe objects (their GPU work could queue behind the stuck
+    collective), and every rank leaves with os._exit(0) -- a process stuck inside a collective cannot be unwound any other way.
+    A leg that returns, or raises, cancels the timer: the normal path is untouched."""
+
+    def __init__(self, seconds, on_timeout):
+        import threading
+        self.seconds, self.fired = seconds, False
+        self._on_timeout = on_timeout
+        self._timer = threading.Timer(seconds, self._fire)
+        self._timer.daemon = True
+
+    def _fire(self):
+        self.fired = True
+        try:
+            self._on_timeout(self.seconds)
+        finally:
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+
+    def __enter__(self):
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._timer.cancel()
+        return False
+
+
 def self_launch(n):
     """`python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks here (one process per GPU under
     torch.distributed.run, rendezvous on 127.0.0.1 and a free port -- the container hostname may not resolve) and hand the
@@ -697,17 +737,44 @@ def main():
                               "images (DESIGN section 7)",
                 **s_cfg}
 
+    def headline_fields():
+        """The contract fields of the line: everything the timed regions above produced, no GPU work."""
+        crops_total = n_step * (1 if strong else world) * args.steps
+        return {
+            "metric": {1: "image-crops/sec (ViT+projector) at 336px, single crop (global only, batch 1)",
+                       3: "image-crops/sec (ViT+projector) at 336px, 1+16 grid"}.get(args.config, "image-crops/sec (ViT+projector) at 336px, 1+4 grid"),
+            "value": round(crops_total / elapsed, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
+            "ms_per_step_repeats": [round(r / args.steps * 1e3, 3) for r in repeats_s],
+            "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic"}
+
+    def strong_leg_timed_out(seconds):
+        """DeadlineGuard's timer thread, every rank: rank 0 prints the headline it holds, without the probe objects."""
+        if rank != 0:
+            time.sleep(2.0)                                  # rank 0's timer was armed within milliseconds of this one: let it print first
+            return
+        msg = (f"timeout: the strong leg did not return within {seconds:.0f} s (a stuck collective?); the headline above is complete -- it was "
+               "timed before the leg started; roofline / path_mfma / box were not probed because their GPU work could queue behind the stuck leg")
+        res = {**headline_fields(),
+               "config": {"workload": WORKLOADS[args.config], "baseline_config": args.config, "crops_per_gpu": n_step,
+                          "images_per_step": IMAGES * world, "grid": f"1+{LOCAL}", "parallelism": f"crop-parallel dp{world} + all-gather of tower features", **extra_cfg},
+               "roofline": None, "cpu_baseline": None, "strong": {"error": msg}}
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(res), flush=True)
+
     strong_obj = None
     if collective and args.config == 2 and not strong:
+        guard = DeadlineGuard(float(os.environ.get("SLIME_BENCH_STRONG_DEADLINE_S", "240")), strong_leg_timed_out)
         try:
-            strong_obj = time_strong()
+            with guard:
+                strong_obj = time_strong()
         except Exception as e:                               # the headline line is printed whatever happens to the second curve
             strong_obj = {"error": f"{type(e).__name__}: {e}"[:400]}
+        if guard.fired:                                      # (a peer that left can make the stuck collective raise here) the timer thread
+            time.sleep(3600)                                 # is printing the headline and ends this process: stay out of its way
 
     if rank == 0:
-        crops_total = n_step * (1 if strong else world) * args.steps
-        value = crops_total / elapsed
-        ms_per_step = elapsed / args.steps * 1e3
         box.mark("probe")
         step_gf = n_step * GF_VIT_PER_CROP + IMAGES * GF_GLOBAL_PER_IMAGE + IMAGES * LOCAL * GF_LOCAL_PER_CROP
         if prefill:
@@ -726,19 +793,9 @@ def main():
         # the driver's line (config 2, 40 crops per GPU) must carry a traffic figure; other launch shapes carry one if profiled
         calib = mfma_stream_calibration(dev, dt, box)
         traffic, traffic_src, traffic_head, traffic_err = pmc_traffic(roof_kernel["rocprof_name"], profiled_shape=(args.config == 2 and not strong and world == 1))
-        workload = {1: "CLIP-ViT-L/14-336, ONE 336x336 crop (global view only, batch 1: BASELINE configs[0] on the HIP path), tower + GatedBlock on the global view -- a latency line: 117 dependent launches on a chip they cannot fill",
-                    2: "CLIP-ViT-L/14-336, 8 images x (1 global + 4 local) 336px crops per GPU (672x672 inputs), tower + gated adapter + post_qformer + MLP projector + spatial merge",
-                    3: "CLIP-ViT-L/14-336, 4 images x (1 global + 16 local) 336px crops = 68 crops in total, crops block-partitioned over the GPUs, all-gather, gated adapter + post_qformer + MLP projector + 4x4 spatial merge on the image-owning rank",
-                    4: "SliME-8B prefill: config-2 encode (40 crops) + visual-token splice into 8 sequences + the attention sub-layer (q/k/v GEMM, RoPE, causal GQA 32q/8kv dh128, o_proj) of 32 Llama-3-8B layers",
-                    5: "video path: 8 frames x (1+4) crops = 40 ViT forwards block-partitioned over the GPUs, all-gather, adapter for all frames, visual-token splice into ONE 9280-position sequence + the attention sub-layer of 32 Llama-3-8B layers (replicated per rank)"}[args.config]
+        workload = WORKLOADS[args.config]
         res = {
-            "metric": {1: "image-crops/sec (ViT+projector) at 336px, single crop (global only, batch 1)",
-                       3: "image-crops/sec (ViT+projector) at 336px, 1+16 grid"}.get(args.config, "image-crops/sec (ViT+projector) at 336px, 1+4 grid"),
-            "value": round(value, 1), "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "ms_per_step_rank_min": round(min(rank_ms), 3), "ms_per_step_rank_max": round(max(rank_ms), 3),
-            "ms_per_step_repeats": [round(r / args.steps * 1e3, 3) for r in repeats_s],
-            "higher_is_better": True, "scaling": C["scaling"], "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            **headline_fields(),
             "config": {"workload": workload, "baseline_config": args.config,
                        "crops_per_gpu": per_rank, "images_per_step": IMAGES * (1 if strong else world), "grid": f"1+{LOCAL}",
                        "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),

@@ -109,3 +109,41 @@ def test_box_sampler_real_sources_never_raise():
     b.mark("timed"); b.stop()
     s = b.summary(("timed",))
     assert "source" in s
+
+
+def test_deadline_guard_prints_the_headline_and_leaves_when_the_second_leg_hangs():
+    """bench.py's DeadlineGuard (round 6): the `strong` leg of the N > 1 line runs before rank 0 prints (one JSON line), so a hang
+    inside it -- a stuck collective on hardware the leg has never run on -- would take the finished weak headline with it.  A leg
+    that overruns its deadline: the callback prints from the timer thread and the process leaves with status 0 while the main
+    thread is still stuck; a leg that returns, or raises, in time: nothing fires."""
+    code = r'''
+import importlib.util, json, sys, time
+spec = importlib.util.spec_from_file_location("b", sys.argv[1]); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+mode = sys.argv[2]
+def cb(seconds): print(json.dumps({"value": 1.0, "strong": {"error": f"timeout after {seconds} s"}}), flush=True)
+if mode == "hang":
+    with b.DeadlineGuard(0.3, cb):
+        time.sleep(30)                      # the stuck collective
+    print("not reached")
+elif mode == "ok":
+    with b.DeadlineGuard(5.0, cb) as g:
+        time.sleep(0.05)
+    time.sleep(0.2); print(json.dumps({"fired": g.fired}))
+else:
+    try:
+        with b.DeadlineGuard(5.0, cb) as g:
+            raise RuntimeError("leg failed")
+    except RuntimeError:
+        time.sleep(0.2); print(json.dumps({"fired": g.fired, "raised": True}))
+'''
+    import json
+    import time
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py"), "hang"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and time.perf_counter() - t0 < 25, (r.returncode, r.stderr[-400:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and "timeout" in json.loads(lines[0])["strong"]["error"]
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py"), "ok"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip()) == {"fired": False}
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py"), "raise"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and json.loads(r.stdout.strip()) == {"fired": False, "raised": True}

@@ -95,6 +95,16 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert len(d["ms_per_step_repeats"]) == 3 and len(d["box"].get("ranks_timed", [0, 0])) == 2
 
 
+def test_bench_gpus_2_strong_leg_deadline_keeps_the_headline():
+    """A strong leg that overruns its deadline (here: a deadline no leg can meet) must not cost the weak headline: the two ranks
+    leave with status 0 and rank 0's line carries the complete headline fields plus `strong: {"error": "timeout ..."}`
+    (bench.DeadlineGuard; the leg has never run on a multi-GPU node, and it runs before the ONE line is printed)."""
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {**ONE_GPU_REHEARSAL, "SLIME_BENCH_STRONG_DEADLINE_S": "0.001"})
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "crops/s" and d["dtype"] == "bf16"
+    assert abs(d["value"] - 80 * 1e3 / d["ms_per_step"]) / d["value"] < 0.01 and len(d["ms_per_step_repeats"]) == 3
+    assert "timeout" in d["strong"]["error"] and d["roofline"] is None and d["config"]["gather_consumed"] is False
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "SLIME_BENCH_SINGLE_DEVICE")}
     import torch
