@@ -45,6 +45,9 @@ import time
 # stream, the tail stream and -- with N > 1 -- RCCL's; streams that share a queue serialise (profiles/r04_collective_hw_queues.txt:
 # 2129 crops/s with 4 queues against 2447 with 8 on the forced-collective line).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC (this pool's host driver supports nothing else): without it RCCL's hipIpcGetMemHandle fails between ranks.  Already
+# exported on the boxes; set here too so that a rank started under a bare torch.distributed.run in a scrubbed environment has it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
