@@ -17,8 +17,10 @@
  *     diagnostic build, libslime_hip_diag.so, compiled from the same sources with -DSLIME_DIAG); calls on
  *     distinct streams with distinct workspaces may run concurrently;
  *   - "T" is the 16-bit MFMA operand type selected by `dtype` (SLIME_BF16 or SLIME_F16); accumulation and the
- *     LayerNorm / softmax statistics are fp32; the tower's residual stream is a 2 x 16-bit SPLIT since ABI 5
- *     (hi = T(h), lo = T(h - hi): 16 significant bits in bf16, 22 in fp16 -- SLIME_EPI_BIAS_RESID_SPLIT_LN), the
+ *     LayerNorm / softmax statistics are fp32; the tower's residual stream is SPLIT since ABI 5: hi = T(h), which is at once the
+ *     next GEMM's operand, and a lower part -- since ABI 7 ONE SIGNED BYTE per element, lo8 = the next 8 bits of h's fp32 pattern
+ *     as the signed distance from hi's pattern (|join(hi, lo8) - h| <= ulp(hi) / 512: 16 significant bits of h with bf16 halves,
+ *     19 with fp16; it was a second T value, 16 / 22 bits, in ABI 5-6) -- SLIME_EPI_BIAS_RESID_SPLIT_LN; 3 bytes per element, not 4; the
  *     Llama decoder layer's is 16-bit as in HF (SLIME_EPI_BIAS_RESID_T); primitive-level fp32 forms remain
  *     (SLIME_EPI_BIAS_RESID_F32[_LN]).
  */
@@ -32,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLIME_ABI_VERSION 6
+#define SLIME_ABI_VERSION 7
 
 enum { SLIME_BF16 = 0, SLIME_F16 = 1, SLIME_F32 = 2, SLIME_U8 = 3 };
 
@@ -53,13 +55,14 @@ enum {
     SLIME_EPI_BIAS_RESID_F32_LN, /* the same, and it prepares the NEXT LayerNorm: x16 = T(C), per-row partial sums (slime_gemm_ex) */
     SLIME_EPI_BIAS_RESID_T,      /* C = T(A*B^T + bias + resid): 16-bit residual stream (Llama decoder layer; slime_gemm_ex)       */
     SLIME_EPI_BIAS_GELU_MIX_T,   /* C[t] = T(g0[t] gelu(A[t] B^T + bias) + g1[t] gelu(A2[t] B^T + bias)): GatedBlock hidden rows, mixed in fp32 (slime_gemm_ex) */
-    SLIME_EPI_BIAS_RESID_SPLIT_LN /* the residual update of BIAS_RESID_F32_LN on a 2 x 16-bit SPLIT residual stream (ABI 5, slime_gemm_ex):
-                                   * h = float(C) + float(lo16) (one fp32 addition: exact up to fp32 rounding -- lo can sit more than 24 bits
-                                   * below hi); c = A*B^T + bias + h; C = T(c), lo16 = T(c - float(C)) (that difference is exact);
+    SLIME_EPI_BIAS_RESID_SPLIT_LN /* the residual update of BIAS_RESID_F32_LN on the SPLIT residual stream (ABI 5; the lower part is a byte since
+                                   * ABI 7; slime_gemm_ex): h = join(C, lo8) -- the fp32 number whose bit pattern is pattern(float(C)) + lo8 2^SH + 2^(SH-1),
+                                   * SH = 8 (bf16) / 5 (fp16): exact, integer arithmetic on IEEE patterns, which are monotonic in the magnitude --;
+                                   * c = A*B^T + bias + h; C = T(c) (RNE), lo8 = clamp((pattern(c) - pattern(float(C))) >> SH, -128, 127) (arithmetic shift);
                                    * stats_out = partial sums of the UNROUNDED c, as _LN (slime_patch_embed_prenorm, the producer of layer 0's
                                    * table, sums the ROUNDED rows T(h): the two definitions differ by ~2^-9 relative per element with random
                                    * sign -- noise far below what a LayerNorm statistic resolves, stated here because both feed the same fold).
-                                   * C is at once the upper half of the stream and the next GEMM's operand (no separate x16 copy). */
+                                   * C is at once the upper part of the stream and the next GEMM's operand (no separate x16 copy). */
 };
 
 int slime_abi_version(void);
@@ -92,7 +95,7 @@ typedef struct {
     const void* resid; int ldr;  /* epilogue BIAS_RESID_T: residual rows T [M, ldr] (may alias C), else NULL / 0     */
     const void* A2;              /* epilogue BIAS_GELU_MIX_T: the second expert's operand rows T [M, lda], else NULL  */
     const float* mix_gates;      /* epilogue BIAS_GELU_MIX_T: fp32 [M, 2] gate pair per row (slime_gate_weights)      */
-    void* lo16; int ldlo;        /* epilogue BIAS_RESID_SPLIT_LN: lower half of the split residual stream, T [M, ldlo], read and written in place */
+    void* lo8; int ldlo;         /* epilogue BIAS_RESID_SPLIT_LN: lower part of the split residual stream, int8 [M, ldlo] (ldlo in BYTES, a multiple of 8; 8-byte aligned), read and written in place */
     const int* row_map;          /* optional (epilogues BIAS_T / BIAS_QUICKGELU_T / BIAS_GELU_T / BIAS_F32 without the LayerNorm fold): output row r
                                   * is stored at C row row_map[r] (device int32 [M], a permutation / scatter into a larger buffer) instead of r:
                                   * lets a GEMM write straight into its consumer's layout (the adapter's token buffer: no merge pass)   */
@@ -143,13 +146,13 @@ int slime_layernorm(const float* x, int ldx, int rows, int D, const float* w, co
  * normalises its rows in registers.  Outputs (any may be NULL except that one of h / x16 is required):
  *   h     f32 [n*(1+P), D]      the residual stream;
  *   x16   T   [n*(1+P), D]      T(h) -- the first GEMM's operand and the upper half of the split residual stream;
- *   lo16  T   [n*(1+P), D]      T(h - float(x16)), the lower half (SLIME_EPI_BIAS_RESID_SPLIT_LN);
+ *   lo8   i8  [n*(1+P), D]      the lower part of the split stream: the next 8 bits of h's pattern relative to x16 (SLIME_EPI_BIAS_RESID_SPLIT_LN);
  *   stats f32 [n*(1+P), D/64, 2] (sum, sum of squares) of the ROUNDED rows per 64-column group (first folded LayerNorm).
  * Limits (checked here, by slime_vit_check at pack time and by every slime_vit_forward*): D in {128, 256, 1024};
  * image % patch == 0 and image % 8 == 0; image / patch <= 24 patches per side; 6 * patch * image < 65535; 16-bit pixels
  * must already be of type T (fp32 pixels are rounded on the way in).  CLIP-L/14-336 and -224 fit; a 448 / 14 tower does not. */
 int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, const void* patch_w_frag, const float* cls, const float* pos,
-                              const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo16, float* stats,
+                              const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo8, float* stats,
                               int dtype, int n, int image, int patch, int kpad, int D, void* stream);
 
 /* Fused multi-head attention, softmax(Q K^T) V with fp32 online softmax; Q is expected PRE-SCALED
@@ -185,7 +188,7 @@ int slime_gate_weights(const float* x, int D, const float* w_gate /* [D,2] */, f
  * clip_encoder.py:38-39, and output-dtype casts :52,56.) */
 int slime_gather_rows(const float* in, int rows_in, int row_off, void* out, int out_dtype,
                       int groups, int rows_out, int C, void* stream);
-/* The same from a 2 x 16-bit split residual stream (ABI 5): in = float(hi) + float(lo), hi / lo T [groups*rows_in, C]. */
+/* The same from the split residual stream (ABI 5; byte lower part since ABI 7): in = join(hi, lo8), hi T / lo8 int8 [groups*rows_in, C]. */
 int slime_gather_rows_split(const void* hi, const void* lo, int dtype, int rows_in, int row_off, void* out, int out_dtype,
                             int groups, int rows_out, int C, void* stream);
 
@@ -309,8 +312,8 @@ size_t slime_vit_workspace_bytes(const slime_vit_desc* d, int n_crops);
  * head_dim 64, the fused front end's geometry limits (slime_patch_embed_prenorm), presence of every weight.  Callers run it
  * when they PACK a tower, so an unsupported geometry fails there with slime_last_error() naming the limit. */
 int slime_vit_check(const slime_vit_desc* d);
-/* The epilogue (SLIME_EPI_*) of the tower's out_proj / fc2 launches in this build: SLIME_EPI_BIAS_RESID_SPLIT_LN (2 x 16-bit split
- * residual stream, ABI 5) -- what a profiler label for those kernels has to be generated with (slime_gemm_kernel_name).  Host-only. */
+/* The epilogue (SLIME_EPI_*) of the tower's out_proj / fc2 launches in this build: SLIME_EPI_BIAS_RESID_SPLIT_LN (split
+ * residual stream: 16-bit operand part + one byte, ABI 7) -- what a profiler label for those kernels has to be generated with (slime_gemm_kernel_name).  Host-only. */
 int slime_vit_residual_epilogue(void);
 
 /* Optional in-situ timing probe: slime_vit_forward_ex records the HIP events `start` / `stop` (hipEvent_t,

@@ -24,7 +24,7 @@ DIAG_LIB_PATH = os.path.join(_HERE, "libslime_hip_diag.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "slime_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 BF16, F16, F32, U8 = 0, 1, 2, 3
 (EPI_BIAS_T, EPI_BIAS_QUICKGELU_T, EPI_BIAS_GELU_T, EPI_BIAS_F32, EPI_BIAS_RESID_F32, EPI_BIAS_RESID_F32_LN, EPI_BIAS_RESID_T,
  EPI_BIAS_GELU_MIX_T, EPI_BIAS_RESID_SPLIT_LN) = range(9)
@@ -48,7 +48,7 @@ class GemmArgs(C.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("dtype", c_int), ("epilogue", c_int),
                 ("ln_stats", c_void_p), ("ln_groups", c_int), ("ln_colsum", c_void_p), ("ln_eps", c_float),
                 ("x16", c_void_p), ("ldx", c_int), ("stats_out", c_void_p), ("B_frag", c_void_p), ("resid", c_void_p), ("ldr", c_int),
-                ("A2", c_void_p), ("mix_gates", c_void_p), ("lo16", c_void_p), ("ldlo", c_int), ("row_map", c_void_p)]
+                ("A2", c_void_p), ("mix_gates", c_void_p), ("lo8", c_void_p), ("ldlo", c_int), ("row_map", c_void_p)]
 
 
 class ResamplerDesc(C.Structure):

@@ -54,14 +54,15 @@ static bool is16(int dt) { return dt == SLIME_BF16 || dt == SLIME_F16; }
 #ifndef SLIME_OPT_ALIAS_WS
 #define SLIME_OPT_ALIAS_WS 1
 #endif
-// Round 5: the residual stream between the layers is a 2 x 16-bit SPLIT (hi = T(h), which IS the next GEMM's operand, lo = T(h - hi))
-// instead of fp32 rows plus a separate T(h) copy: the out_proj / fc2 epilogues move 8 bytes per element instead of 10
+// Round 5: the residual stream between the layers is SPLIT (hi = T(h), which IS the next GEMM's operand, + a lower part) instead of
+// fp32 rows plus a separate T(h) copy; round 6 (ABI 7): the lower part is one signed byte per element (common.h resid_delta): the
+// out_proj / fc2 epilogues move 6 bytes per element -- 8 with a 16-bit lower part (round 5), 10 with the fp32 stream
 // (SLIME_EPI_BIAS_RESID_SPLIT_LN).  0 = the fp32 stream of rounds 1-4 (tools/build_variants.sh A/B).
 #ifndef SLIME_OPT_SPLIT_RESID
 #define SLIME_OPT_SPLIT_RESID 1
 #endif
 struct VitPlan {
-    size_t xn, qkv, ctx, ff, h, stats, total;   // offsets (h: the fp32 residual rows, or the lower half of the split stream)
+    size_t xn, qkv, ctx, ff, h, stats, total;   // offsets (h: the fp32 residual rows, or the lower part of the split stream: one byte per element since ABI 7)
 };
 
 static VitPlan vit_plan(const slime_vit_desc* d, int n) {
@@ -70,7 +71,7 @@ static VitPlan vit_plan(const slime_vit_desc* d, int n) {
     VitPlan p{};
     size_t off = 0;
     auto take = [&](size_t b) { size_t o = align_up(off, 256); off = o + b; return o; };
-    p.h = take(M * D * (SLIME_OPT_SPLIT_RESID ? 2 : 4));
+    p.h = take(M * D * (SLIME_OPT_SPLIT_RESID ? 1 : 4));
     p.xn = take(M * D * 2);
     const size_t ff_bytes = M * (size_t)d->inter * 2;
 #if SLIME_OPT_ALIAS_WS
@@ -185,7 +186,7 @@ static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, i
     float* stats = (float*)(w + p.stats);
     const int G = D / 64;
 #if SLIME_OPT_SPLIT_RESID
-    // residual stream = (xn, lo): xn = T(h) is the upper half AND the operand of the q/k/v / fc1 GEMMs, lo = T(h - xn)
+    // residual stream = (xn, lo): xn = T(h) is the upper part AND the operand of the q/k/v / fc1 GEMMs, lo = one signed byte per element (common.h resid_delta)
     void* lo = w + p.h;
     float* h = nullptr;
 #else
@@ -233,7 +234,7 @@ static int vit_run(const slime_vit_desc* d, const void* pixels, int pix_dtype, i
         auto resid_update = [&](slime_gemm_args& r, bool with_ln) {
 #if SLIME_OPT_SPLIT_RESID
             (void)with_ln;                                   // the last layer's partial sums are written and never read
-            r.C = xn; r.ldc = D; r.lo16 = lo; r.ldlo = D; r.stats_out = stats; r.epilogue = SLIME_EPI_BIAS_RESID_SPLIT_LN;
+            r.C = xn; r.ldc = D; r.lo8 = lo; r.ldlo = D; r.stats_out = stats; r.epilogue = SLIME_EPI_BIAS_RESID_SPLIT_LN;
 #else
             r.C = h; r.ldc = D;
             r.epilogue = with_ln ? SLIME_EPI_BIAS_RESID_F32_LN : SLIME_EPI_BIAS_RESID_F32;

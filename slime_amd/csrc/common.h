@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // 16-bit MFMA operand types.  `bits` are carried around as raw u32 words.
 struct BF16 {
     static constexpr int id = SLIME_BF16;
+    static constexpr int RESID_SH = 8;      // fp32 pattern bits below the 8 that follow a bf16 significand (resid_delta / resid_join)
     static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -62,6 +63,7 @@ struct BF16 {
 };
 struct F16 {
     static constexpr int id = SLIME_F16;
+    static constexpr int RESID_SH = 5;      // ... below the 8 that follow an fp16 significand
     static __device__ __forceinline__ f32x4 mfma16(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -131,6 +133,34 @@ __device__ __forceinline__ V ld_stream(const V* p) {
 #else
     return *p;
 #endif
+}
+
+// ---- the residual stream's lower part (ABI 7): ONE SIGNED BYTE per element -------------------------------------------------------
+// The stream is kept as hi = T(h) (RNE: hi IS the next GEMM's operand) and d8 = the next 8 bits of h's fp32 pattern, stored as the
+// signed distance of h's pattern from hi's in units of 2^SH (SH = 8 for bf16, 5 for fp16), rounded DOWN, and read back at the
+// middle of its cell:
+//     d8 = floor((pattern(h) - pattern(float(hi))) / 2^SH)  in [-128, 127],      join = pattern(float(hi)) + d8 2^SH + 2^(SH-1).
+// IEEE patterns of one sign are monotonic in the magnitude, so this holds across binade boundaries and whichever way hi was rounded:
+// |h - hi| <= ulp(hi) / 2 puts the distance in [-2^(SH+7), 2^(SH+7)], i.e. d8 in [-128, 128], and +128 -- an exact tie that RNE rounded
+// down -- is stored as 127, whose cell centre is still within half a cell of h.  So |join - h| <= 2^(SH-1) patterns = ulp(hi) / 512 in
+// EVERY case, without bias: 16 significant bits of h with bf16 halves (what the 2 x bf16 stream of ABI 5-6 guaranteed), 19 with fp16
+// halves (22 before; fp32 has 24; below fp16's normal range, |h| < 2^-14, hi's spacing is fixed while the byte counts cells of its fp32
+// pattern, and the stream keeps what hi keeps: 2^-25, where the 16-bit lower part bottomed out too).  Both directions are integer arithmetic on the patterns -- exact, no exponent handling, the same
+// operations in every kernel that touches the stream.  6 bytes per element cross the fabric in a residual update (2 + 1 in, 2 + 1
+// out) instead of 8; measured with the traffic alone changed (round 6, profiles/r06_lo8_traffic_ablation.txt): two-stream tower
+// -2.1 %, stand-alone launches unchanged.
+template <typename T>
+__device__ __forceinline__ int resid_delta(float h, float hi_f) {
+    const int d = (__float_as_int(h) - __float_as_int(hi_f)) >> T::RESID_SH;      // arithmetic shift: floor
+    return min(max(d, -128), 127);
+}
+template <typename T>
+__device__ __forceinline__ float resid_join(float hi_f, int d8) {
+    return __int_as_float(__float_as_int(hi_f) + d8 * (1 << T::RESID_SH) + (1 << (T::RESID_SH - 1)));
+}
+__device__ __forceinline__ int sext_byte(unsigned w, int k) { return (int)(w << (24 - 8 * k)) >> 24; }   // v_bfe_i32
+__device__ __forceinline__ unsigned pack_bytes(int b0, int b1, int b2, int b3) {
+    return (unsigned)(b0 & 0xff) | ((unsigned)(b1 & 0xff) << 8) | ((unsigned)(b2 & 0xff) << 16) | ((unsigned)b3 << 24);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

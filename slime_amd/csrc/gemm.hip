@@ -257,16 +257,17 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
             }
         }
     } else if constexpr (EPI == SLIME_EPI_BIAS_RESID_SPLIT_LN) {
-        // The residual update on a 2 x 16-bit SPLIT stream (round 5): h = float(hi) + float(lo) (one fp32 addition: exact up to fp32
-        // rounding -- lo's exponent can sit more than 24 bits below hi's), c = acc + (bias + h), hi' = T(c), lo' = T(c - float(hi'))
-        // (that difference is exact), partial sums of the UNROUNDED c as in BIAS_RESID_F32_LN (the front end, producer of layer 0's
-        // table, sums the rounded rows: include/slime_hip.h states the difference).  hi' IS the next GEMM's operand: 8 bytes per element cross the fabric here (2 + 2 in, 2 + 2 out)
-        // instead of 10 (4 in, 4 + 2 out); what is kept of c are 16 (bf16) / 22 (fp16) significant bits instead of 24.
-        // C (= hi) and lo are read and written in place and vmcnt counts stores: both planes are fetched one 16-row step ahead
-        // (one step, not two as the fp32 epilogue: two planes' addresses + unpacked halves must fit the direct-B kernel's 128 VGPRs).
+        // The residual update on the SPLIT stream (round 5; ABI 7: the lower part is one signed byte per element, common.h resid_delta /
+        // resid_join): h = join(hi, d8) (exact), c = acc + (bias + h), hi' = T(c), d8' = delta(c, hi'), partial sums of the UNROUNDED c as
+        // in BIAS_RESID_F32_LN (the front end, producer of layer 0's table, sums the rounded rows: include/slime_hip.h states the
+        // difference).  hi' IS the next GEMM's operand: 6 bytes per element cross the fabric here (2 + 1 in, 2 + 1 out) instead of 8
+        // (ABI 5/6: two 16-bit halves) or 10 (fp32 stream + 16-bit copy); what is kept of c are 16 (bf16) / 19 (fp16) significant bits.
+        // C (= hi) and lo8 are read and written in place and vmcnt counts stores: both planes are fetched one 16-row step ahead
+        // (two and three steps ahead measured the same, profiles/r06_resid_lookahead_ab.txt: the epilogue is bound by bytes).
         static_assert(NP % 2 == 0, "BIAS_RESID_SPLIT_LN: a wave must own whole 64-column groups (the stores sit in the per-group loop: a 32-column "
                                    "wave tile would store nothing -- round 6, profiles/r06_ring8_tiles.txt)");
-        u32x4 rb[2][NP][2];
+        u32x4 rh[2][NP];
+        u32x2 rl[2][NP];
         char* Hi = reinterpret_cast<char*>(g.C);
         char* Lo = g.lo;
         auto load_step = [&](int i, int buf) {
@@ -274,8 +275,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
             if constexpr (!FULL) row = min(row, g.M - 1);
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                rb[buf][p][0] = ld_stream(reinterpret_cast<const u32x4*>(Hi + ((size_t)row * g.ldc + col_base + 32 * p) * 2));
-                rb[buf][p][1] = ld_stream(reinterpret_cast<const u32x4*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p) * 2));
+                rh[buf][p] = ld_stream(reinterpret_cast<const u32x4*>(Hi + ((size_t)row * g.ldc + col_base + 32 * p) * 2));
+                rl[buf][p] = ld_stream(reinterpret_cast<const u32x2*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p)));
             }
         };
         load_step(0, 0);
@@ -289,20 +290,26 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& g, f32x4 (&acc)[MI
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int p = 2 * pp + h2;
-                    const u32x4 rh = rb[i & 1][p][0], rl = rb[i & 1][p][1];
-                    u32x4 w, wl;
+                    const u32x4 hw = rh[i & 1][p];
+                    const u32x2 lw = rl[i & 1][p];
+                    u32x4 w;
+                    int nd[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {                    // word e = columns 2e, 2e+1 of the lane's 8: accumulator block 2p + (e >> 1)
-                        const float c0 = acc[i][2 * p + (e >> 1)][(2 * e) & 3] + (bias[p][2 * e] + (T::lo(rh[e]) + T::lo(rl[e])));
-                        const float c1 = acc[i][2 * p + (e >> 1)][(2 * e + 1) & 3] + (bias[p][2 * e + 1] + (T::hi(rh[e]) + T::hi(rl[e])));
+                        const float h0 = resid_join<T>(T::lo(hw[e]), sext_byte(lw[e >> 1], 2 * (e & 1)));
+                        const float h1 = resid_join<T>(T::hi(hw[e]), sext_byte(lw[e >> 1], 2 * (e & 1) + 1));
+                        const float c0 = acc[i][2 * p + (e >> 1)][(2 * e) & 3] + (bias[p][2 * e] + h0);
+                        const float c1 = acc[i][2 * p + (e >> 1)][(2 * e + 1) & 3] + (bias[p][2 * e + 1] + h1);
                         acc[i][2 * p + (e >> 1)][(2 * e) & 3] = c0;
                         acc[i][2 * p + (e >> 1)][(2 * e + 1) & 3] = c1;
                         w[e] = T::pack2(c0, c1);
-                        wl[e] = T::pack2(c0 - T::lo(w[e]), c1 - T::hi(w[e]));
+                        nd[2 * e] = resid_delta<T>(c0, T::lo(w[e]));
+                        nd[2 * e + 1] = resid_delta<T>(c1, T::hi(w[e]));
                     }
                     if (in_range(row)) {
                         st_stream(reinterpret_cast<u32x4*>(Hi + ((size_t)row * g.ldc + col_base + 32 * p) * 2), w);
-                        st_stream(reinterpret_cast<u32x4*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p) * 2), wl);
+                        st_stream(reinterpret_cast<u32x2*>(Lo + ((size_t)row * g.ldlo + col_base + 32 * p)),
+                                  u32x2{pack_bytes(nd[0], nd[1], nd[2], nd[3]), pack_bytes(nd[4], nd[5], nd[6], nd[7])});
                     }
                     // partial sums in the element order of BIAS_RESID_F32_LN
 #pragma unroll
@@ -2221,9 +2228,9 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
                        a->epilogue == SLIME_EPI_BIAS_F32),
                       "gemm: row_map goes with the plain T / fp32 epilogues (BIAS_T, BIAS_QUICKGELU_T, BIAS_GELU_T, BIAS_F32; no LayerNorm fold)");
     if (a->epilogue == SLIME_EPI_BIAS_RESID_SPLIT_LN)
-        SLIME_REQUIRE(a->lo16 && a->stats_out && a->ldlo >= N && a->ldlo % 8 == 0 && ((uintptr_t)a->lo16 % 16) == 0 &&
-                      ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0 && a->lo16 != a->C,
-                      "gemm: BIAS_RESID_SPLIT_LN needs the split residual stream C = hi T [M, ldc], lo16 T [M, ldlo] and stats_out [M, N/64, 2]");
+        SLIME_REQUIRE(a->lo8 && a->stats_out && a->ldlo >= N && a->ldlo % 8 == 0 && ((uintptr_t)a->lo8 % 8) == 0 &&
+                      ((uintptr_t)a->stats_out % 8) == 0 && N % 64 == 0 && a->lo8 != a->C,
+                      "gemm: BIAS_RESID_SPLIT_LN needs the split residual stream C = hi T [M, ldc], lo8 int8 [M, ldlo] and stats_out [M, N/64, 2]");
     if (a->epilogue == SLIME_EPI_BIAS_RESID_T)
         SLIME_REQUIRE(a->resid && a->ldr >= N && a->ldr % 8 == 0 && ((uintptr_t)a->resid % 16) == 0,
                       "gemm: BIAS_RESID_T needs resid T [M, ldr >= N] (16-byte aligned, ldr a multiple of 8)");
@@ -2235,7 +2242,7 @@ extern "C" int slime_gemm_ex(const slime_gemm_args* a, void* stream) {
     GemmArgs g{(const char*)a->A, (const char*)a->B, a->bias, a->C, lda, ldc, M, N, K, g_group_m, g_dbg,
                a->ln_stats, a->ln_groups, a->ln_colsum, a->ln_eps, (char*)a->x16, a->ldx, a->stats_out,
                frag_ok ? (const char*)a->B_frag : nullptr, g_db_abl, (const char*)a->resid, a->ldr, (const char*)a->A2, a->mix_gates,
-               (char*)a->lo16, a->ldlo, (const char*)a->B_frag, a->row_map};
+               (char*)a->lo8, a->ldlo, (const char*)a->B_frag, a->row_map};
     hipStream_t s = (hipStream_t)stream;
     if (a->dtype == SLIME_BF16) return launch_T<BF16>(g, a->epilogue, s);
     if (a->dtype == SLIME_F16) return launch_T<F16>(g, a->epilogue, s);

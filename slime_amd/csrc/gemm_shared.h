@@ -24,7 +24,7 @@ struct GemmArgs {
     const char* resid; int ldr;
     // epilogue BIAS_GELU_MIX_T: second stacked operand (rows of the other expert) and the per-token gate pair
     const char* A2; const float* mix_gates;
-    // epilogue BIAS_RESID_SPLIT_LN: lower half of the 2 x 16-bit residual stream (C is the upper half), read and written in place
+    // epilogue BIAS_RESID_SPLIT_LN: lower part of the split residual stream, one signed byte per element (C is the upper part), read and written in place; ldlo in bytes
     char* lo; int ldlo;
     // the fragment-order image whatever the shape (Bf is set only where the direct-B kernel is eligible): the LDS-staged kernels
     // DMA from it when B == NULL

@@ -18,7 +18,7 @@
 //      3 x CW/16 MFMAs of 16x16x32 per k-step, product transposed (mfma(W, X)) so that a lane ends with 8 consecutive columns;
 //   4. epilogue in registers: + position row, two-pass LayerNorm statistics (lane -> the wave's four 16-lane rows by permlane
 //      swaps -> across the waves through 3 KB of LDS, summed in wave order: fixed, batch-independent), affine, then the outputs
-//      the layer stack wants: the fp32 residual rows (or their 2 x 16-bit split), T(h) and its per-64-column partial sums
+//      the layer stack wants: the fp32 residual rows (or their split form: T(h) + one byte), T(h) and its per-64-column partial sums
 //      (the first folded LayerNorm of slime_gemm_ex).  Row 0 of every crop (class token + position 0) is input independent; the
 //      workgroup that owns a crop's first patch rows writes it.
 #include "gemm_shared.h"
@@ -75,7 +75,10 @@ __device__ __forceinline__ void pe_cls_row(const PEArgs& a, const long grow, con
             const unsigned pk = T::pack2(y0, y1);
             const float r0 = T::lo(pk), r1 = T::hi(pk);
             if (a.x16) *reinterpret_cast<unsigned*>(a.x16 + ((size_t)grow * D + c + j) * 2) = pk;
-            if (a.lo) *reinterpret_cast<unsigned*>(a.lo + ((size_t)grow * D + c + j) * 2) = T::pack2(y0 - r0, y1 - r1);
+            if (a.lo) {                                   // the stream's lower part: one signed byte per element (common.h resid_delta)
+                a.lo[(size_t)grow * D + c + j] = (char)resid_delta<T>(y0, r0);
+                a.lo[(size_t)grow * D + c + j + 1] = (char)resid_delta<T>(y1, r1);
+            }
             sx += r0; sx += r1; sq = fmaf(r0, r0, sq); sq = fmaf(r1, r1, sq);
         }
         if (a.stats) {
@@ -297,11 +300,11 @@ __global__ void __launch_bounds__(NW * 64) patch_embed_kernel(PEArgs a) {
                         *reinterpret_cast<f32x4*>(a.h + off + 4) = f32x4{y[4], y[5], y[6], y[7]};
                     }
                     if (a.x16) *reinterpret_cast<u32x4*>(a.x16 + off * 2) = w;
-                    if (a.lo) {
-                        float d[8];
+                    if (a.lo) {                           // the stream's lower part: one signed byte per element (common.h resid_delta)
+                        int d[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) d[e] = y[e] - r[e];
-                        *reinterpret_cast<u32x4*>(a.lo + off * 2) = pack8<T>(d);
+                        for (int e = 0; e < 8; ++e) d[e] = resid_delta<T>(y[e], r[e]);
+                        *reinterpret_cast<u32x2*>(a.lo + off) = u32x2{pack_bytes(d[0], d[1], d[2], d[3]), pack_bytes(d[4], d[5], d[6], d[7])};
                     }
                 }
                 // partial sums of the ROUNDED row per 64-column group (what the consuming GEMM multiplies), lane-local first
@@ -362,11 +365,11 @@ int slime_patch_embed_geometry(int image, int patch, int kpad, int D, size_t* ld
 }
 
 extern "C" int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, const void* patch_w_frag, const float* cls, const float* pos,
-                                         const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo16, float* stats,
+                                         const float* ln_w, const float* ln_b, float eps, float* h, void* x16, void* lo8, float* stats,
                                          int dtype, int n, int image, int patch, int kpad, int D, void* stream) {
     SLIME_REQUIRE(pixels && patch_w_frag && cls && pos && ln_w && ln_b && n > 0, "patch_embed: bad input");
     SLIME_REQUIRE(h || x16, "patch_embed: no output requested (h and / or x16)");
-    SLIME_REQUIRE(!lo16 || x16, "patch_embed: the split residual (lo16) comes with its upper half x16");
+    SLIME_REQUIRE(!lo8 || x16, "patch_embed: the split residual's lower part (lo8) comes with its upper part x16");
     SLIME_REQUIRE(!stats || x16, "patch_embed: stats are the partial sums of x16");
     SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "patch_embed: dtype must be BF16 or F16");
     SLIME_REQUIRE(pix_dtype == SLIME_F32 || pix_dtype == dtype, "patch_embed: 16-bit pixels must already be in the tower dtype");
@@ -375,9 +378,9 @@ extern "C" int slime_patch_embed_prenorm(const void* pixels, int pix_dtype, cons
     const int g = image / patch;
     SLIME_REQUIRE(((uintptr_t)pixels % 16) == 0 && ((uintptr_t)patch_w_frag % 16) == 0 && ((uintptr_t)pos % 16) == 0 &&
                   ((uintptr_t)ln_w % 16) == 0 && ((uintptr_t)ln_b % 16) == 0 && (!h || (uintptr_t)h % 16 == 0) &&
-                  (!x16 || (uintptr_t)x16 % 16 == 0) && (!lo16 || (uintptr_t)lo16 % 16 == 0) && (!stats || (uintptr_t)stats % 8 == 0),
+                  (!x16 || (uintptr_t)x16 % 16 == 0) && (!lo8 || (uintptr_t)lo8 % 8 == 0) && (!stats || (uintptr_t)stats % 8 == 0),
                   "patch_embed: pointers must be 16-byte aligned");
-    PEArgs a{pixels, (const char*)patch_w_frag, cls, pos, ln_w, ln_b, eps, h, (char*)x16, (char*)lo16, stats, n, image, patch, kpad, g};
+    PEArgs a{pixels, (const char*)patch_w_frag, cls, pos, ln_w, ln_b, eps, h, (char*)x16, (char*)lo8, stats, n, image, patch, kpad, g};
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SLIME_F16)
         return pix_dtype == SLIME_F32 ? launch_pe_d<F16, float>(a, D, lds, s) : launch_pe_d<F16, unsigned short>(a, D, lds, s);

@@ -327,7 +327,7 @@ extern "C" int slime_gather_rows(const float* in, int rows_in, int row_off, void
     return SLIME_OK;
 }
 
-// The same from a 2 x 16-bit split residual stream (tower, round 5): in = float(hi) + float(lo), 8 elements per lane per step.
+// The same from the split residual stream (tower, round 5; ABI 7: the lower part is one signed byte per element): in = join(hi, lo8), 8 elements per lane per step.
 template <typename T>
 __global__ void __launch_bounds__(256) gather_rows_split_kernel(const char* hi, const char* lo, int rows_in, int row_off, void* out,
                                                                 int out_dtype, long total, int rows_out, int C) {
@@ -335,12 +335,16 @@ __global__ void __launch_bounds__(256) gather_rows_split_kernel(const char* hi, 
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= total) return;
     const long g = r / rows_out, i = r % rows_out;
-    const size_t src = ((size_t)g * rows_in + row_off + i) * C * 2;
+    const size_t src = ((size_t)g * rows_in + row_off + i) * C;
     for (int c = lane * 8; c < C; c += 512) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(hi + src + (size_t)c * 2), b = *reinterpret_cast<const u32x4*>(lo + src + (size_t)c * 2);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(hi + (src + c) * 2);
+        const u32x2 b = *reinterpret_cast<const u32x2*>(lo + src + c);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[2 * e] = T::lo(a[e]) + T::lo(b[e]); v[2 * e + 1] = T::hi(a[e]) + T::hi(b[e]); }
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = resid_join<T>(T::lo(a[e]), sext_byte(b[e >> 1], 2 * (e & 1)));
+            v[2 * e + 1] = resid_join<T>(T::hi(a[e]), sext_byte(b[e >> 1], 2 * (e & 1) + 1));
+        }
         if (out_dtype == SLIME_F32) {
             float* d = reinterpret_cast<float*>(out) + (size_t)r * C + c;
             *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
@@ -359,7 +363,7 @@ extern "C" int slime_gather_rows_split(const void* hi, const void* lo, int dtype
     SLIME_REQUIRE(dtype == SLIME_BF16 || dtype == SLIME_F16, "gather_rows_split: the stream halves are BF16 or F16");
     SLIME_REQUIRE(out_dtype == SLIME_F32 || out_dtype == SLIME_BF16 || out_dtype == SLIME_F16, "gather_rows_split: bad out dtype");
     SLIME_REQUIRE(row_off >= 0 && row_off + rows_out <= rows_in, "gather_rows_split: window outside the group");
-    SLIME_REQUIRE(((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo % 16) == 0 && ((uintptr_t)out % 16) == 0, "gather_rows_split: 16-byte alignment");
+    SLIME_REQUIRE(((uintptr_t)hi % 16) == 0 && ((uintptr_t)lo % 8) == 0 && ((uintptr_t)out % 16) == 0, "gather_rows_split: hi / out 16-byte, lo8 8-byte aligned");
     const long total = (long)groups * rows_out;
     const dim3 grid((unsigned)((total + 3) / 4)), block(256);
     if (dtype == SLIME_F16)

@@ -147,17 +147,41 @@ def gemm_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return x16, stats
 
 
+def _resid_shift(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return 8
+    if dtype == torch.float16:
+        return 5
+    raise ValueError(f"the split residual stream's upper part is bf16 or fp16, not {dtype}")
+
+
+def resid_split(h: torch.Tensor, dtype: torch.dtype):
+    """fp32 rows -> the tower's SPLIT residual stream (include/slime_hip.h, ABI 7; a torch restatement of csrc/common.h resid_delta):
+    hi = T(h) (RNE) and lo8 = floor((pattern(h) - pattern(float(hi))) / 2^SH) clamped to int8, SH = 8 (bf16) / 5 (fp16)."""
+    sh = _resid_shift(dtype)
+    hi = h.to(dtype)
+    d = (h.float().contiguous().view(torch.int32) - hi.float().view(torch.int32)) >> sh          # int32 >> is arithmetic: floor
+    return hi, d.clamp(-128, 127).to(torch.int8)
+
+
+def resid_join(hi: torch.Tensor, lo8: torch.Tensor) -> torch.Tensor:
+    """The fp32 rows a split residual stream holds (csrc/common.h resid_join): pattern(float(hi)) + lo8 2^SH + 2^(SH-1)."""
+    sh = _resid_shift(hi.dtype)
+    return (hi.float().contiguous().view(torch.int32) + lo8.to(torch.int32) * (1 << sh) + (1 << (sh - 1))).view(torch.float32)
+
+
 def gemm_resid_split(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[torch.Tensor], hi: torch.Tensor, lo: torch.Tensor,
                      w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """SLIME_EPI_BIAS_RESID_SPLIT_LN on the 2 x 16-bit split residual stream (hi, lo: T [M, N], updated in place):
-    c = a @ w.T + bias + (float(hi) + float(lo)); hi = T(c); lo = T(c - float(hi)).  Returns stats [M, N/64, 2] (partial sums of c)."""
+    """SLIME_EPI_BIAS_RESID_SPLIT_LN on the split residual stream (hi: T [M, N], lo: int8 [M, N], updated in place):
+    c = a @ w.T + bias + resid_join(hi, lo); hi, lo = resid_split(c).  Returns stats [M, N/64, 2] (partial sums of c)."""
+    assert lo.dtype == torch.int8 and lo.stride(1) == 1, "the stream's lower part is one signed byte per element (ABI 7)"
     lib = _lib.load()
     M, K = a.shape
     N = (w if w is not None else w_frag).shape[0]
     stats = torch.empty((M, N // 64, 2), dtype=torch.float32, device=a.device)
     g = _lib.GemmArgs(A=_ptr(a), lda=a.stride(0), B=_ptr(w), bias=_ptr(bias), C=_ptr(hi), ldc=hi.stride(0), M=M, N=N, K=K,
                       dtype=dtype_code(a.dtype), epilogue=_lib.EPI_BIAS_RESID_SPLIT_LN, stats_out=_ptr(stats), B_frag=_ptr(w_frag),
-                      lo16=_ptr(lo), ldlo=lo.stride(0))
+                      lo8=_ptr(lo), ldlo=lo.stride(0))
     _lib.check(lib.slime_gemm_ex(C.byref(g), _stream()), "slime_gemm_ex")
     return stats
 
@@ -165,7 +189,7 @@ def gemm_resid_split(a: torch.Tensor, w: Optional[torch.Tensor], bias: Optional[
 def patch_embed_prenorm(pixels: torch.Tensor, patch_w_frag: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, ln_w: torch.Tensor,
                         ln_b: torch.Tensor, eps: float, dtype: torch.dtype, image: int, patch: int, kpad: int, want_h=True, want_x16=True,
                         want_lo=False):
-    """slime_patch_embed_prenorm: pixels [n,3,image,image] (fp32 or T) -> (h fp32 [n*(1+P), D] | None, x16 T | None, lo T | None,
+    """slime_patch_embed_prenorm: pixels [n,3,image,image] (fp32 or T) -> (h fp32 [n*(1+P), D] | None, x16 T | None, lo int8 | None,
     stats [n*(1+P), D/64, 2] | None)."""
     lib = _lib.load()
     n, D = pixels.shape[0], cls.shape[0]
@@ -173,7 +197,7 @@ def patch_embed_prenorm(pixels: torch.Tensor, patch_w_frag: torch.Tensor, cls: t
     dev = pixels.device
     h = torch.empty((rows, D), dtype=torch.float32, device=dev) if want_h else None
     x16 = torch.empty((rows, D), dtype=dtype, device=dev) if want_x16 else None
-    lo = torch.empty((rows, D), dtype=dtype, device=dev) if want_lo else None
+    lo = torch.empty((rows, D), dtype=torch.int8, device=dev) if want_lo else None
     stats = torch.empty((rows, D // 64, 2), dtype=torch.float32, device=dev) if want_x16 else None
     _lib.check(lib.slime_patch_embed_prenorm(_ptr(pixels), dtype_code(pixels.dtype), _ptr(patch_w_frag), _ptr(cls), _ptr(pos), _ptr(ln_w),
                                              _ptr(ln_b), float(eps), _ptr(h), _ptr(x16), _ptr(lo), _ptr(stats), dtype_code(dtype), n, image,

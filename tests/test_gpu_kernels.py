@@ -466,10 +466,10 @@ def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
     per_row = ((h.cpu() - ref).norm(dim=1) / ref.norm(dim=1)).max()
     assert float(per_row) < 5 * TOL_F32, float(per_row)               # no stray row (class-token rows, workgroup seams, last patch row)
     assert torch.equal(x16, h.to(dt))                                  # the GEMM operand is T(h) exactly
-    d = h - x16.float()
-    assert torch.equal(lo, d.to(dt))                                   # the split stream's lower half is T(h - T(h)) exactly
-    bits = 16 if dt == torch.bfloat16 else 21
-    assert float((((x16.float() + lo.float()) - h).abs() - h.abs() * 2.0 ** -bits).max()) <= (0.0 if dt == torch.bfloat16 else 2.0 ** -24)
+    hi_ref, lo_ref = ops.resid_split(h, dt)
+    assert lo.dtype == torch.int8 and torch.equal(lo, lo_ref)          # the split stream's lower part is the byte of the host restatement, exactly
+    bits = 16 if dt == torch.bfloat16 else 19
+    assert float(((ops.resid_join(x16, lo) - h).abs() - h.abs() * 2.0 ** -bits).max()) <= (0.0 if dt == torch.bfloat16 else 2.0 ** -25)
     xr = x16.float().view(n * S, D // 64, 64)
     assert rel_l2(stats[..., 0], xr.sum(-1)) < 1e-5 and rel_l2(stats[..., 1], (xr * xr).sum(-1)) < 1e-5
     # pixels already in T: the same bits (fp32 pixels are rounded to T on the way in, clip_encoder.py:55)
@@ -484,7 +484,7 @@ def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
     st = ops.tower_hidden_states(pt, px)
     assert st.shape[0] == 1 and rel_l2(st[0].reshape(n * S, D).cpu(), ref) < (2.0 ** -15 if dt == torch.bfloat16 else 2e-5) + TOL_F32
     lib = _lib.load()
-    with pytest.raises(_lib.SlimeHipError, match="lo16"):              # the lower half comes with its upper half
+    with pytest.raises(_lib.SlimeHipError, match="lo8"):               # the lower part comes with its upper part
         _lib.check(lib.slime_patch_embed_prenorm(px.data_ptr(), _lib.F32, T["patch_w_frag"].data_ptr(), T["cls"].data_ptr(), T["pos"].data_ptr(),
                                                  T["pre_ln_w"].data_ptr(), T["pre_ln_b"].data_ptr(), 1e-5, h.data_ptr(), None, lo.data_ptr(), None,
                                                  ops.dtype_code(dt), n, cfg.image_size, cfg.patch_size, kpad, D, 0))
@@ -496,10 +496,11 @@ def test_patch_embed_prenorm_vs_oracle(dev, dt, geom):
                                         (1731, 1024, 1024, 11), (1731, 1024, 1024, 1), (1731, 1024, 1024, 18), (577, 1024, 4096, 18),
                                         (1731, 1024, 1024, 19), (5193, 1024, 4096, 19), (11540, 1024, 1024, 19), (100, 1024, 1024, 19)])
 def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
-    """SLIME_EPI_BIAS_RESID_SPLIT_LN (round 5): the residual update on a 2 x 16-bit split stream.  Against fp32 torch on the same
-    operands: hi' = T(c) EXACTLY for c = the kernel's own fp32 result (checked through the fp32 epilogue, which computes the same c
-    when fed h = float(hi) + float(lo)), lo' = T(c - hi') exactly, hi' + lo' within 2^-16 (bf16) / 2^-21 (fp16) of c, partial sums
-    of c; and bit-equal across kernel families (auto dispatch with / without the fragment image, forced tiles)."""
+    """SLIME_EPI_BIAS_RESID_SPLIT_LN (round 5; ABI 7: the lower part is one signed byte): the residual update on the split stream.
+    Against fp32 torch on the same operands: hi' = T(c) EXACTLY for c = the kernel's own fp32 result (checked through the fp32
+    epilogue, which computes the same c when fed h = join(hi, lo8)), lo8' = the host restatement's byte exactly, join(hi', lo8')
+    within 2^-16 (bf16) / 2^-19 (fp16) of c, partial sums of c; and bit-equal across kernel families (auto dispatch with / without
+    the fragment image, forced tiles)."""
     from slime_amd import ops, _lib
     a = _rand((M, K), dtype, dev, 1)
     w = _rand((N, K), dtype, dev, 2, K ** -0.5)
@@ -507,9 +508,8 @@ def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
     wf = ops.pack_b_frag(w)
     h0 = _rand((M, N), torch.float32, dev, 4, 2.0) + 0.3
     h0[:, 5] *= 50.0                                                   # an outlier channel
-    hi0 = h0.to(dtype)
-    lo0 = (h0 - hi0.float()).to(dtype)
-    hsum = hi0.float() + lo0.float()                                   # what the stream holds
+    hi0, lo0 = ops.resid_split(h0, dtype)
+    hsum = ops.resid_join(hi0, lo0)                                    # what the stream holds
 
     def run(with_frag, with_w=True):
         hi, lo = hi0.clone(), lo0.clone()
@@ -526,11 +526,11 @@ def test_gemm_split_residual_epilogue(dev, dtype, M, N, K, tile):
     ref = hsum.double() + a.double() @ w.double().t() + bias.double()
     assert rel_l2(c, ref) < TOL_F32
     assert torch.equal(hi, c.to(dtype)), "upper half must be T(c)"
-    assert torch.equal(lo, (c - hi.float()).to(dtype)), "lower half must be T(c - T(c))"
-    # what the pair keeps of c: 16 (bf16) / 21 (fp16) significant bits; fp16's lower half bottoms out at its subnormal spacing 2^-24
-    bits = 16 if dtype == torch.bfloat16 else 21
-    err = ((hi.float() + lo.float()) - c).abs() - c.abs() * 2.0 ** -bits
-    assert float(err.max()) <= (0.0 if dtype == torch.bfloat16 else 2.0 ** -24), float(err.max())
+    assert lo.dtype == torch.int8 and torch.equal(lo, ops.resid_split(c, dtype)[1]), "lower part must be the byte of the host restatement"
+    # what the pair keeps of c: 16 (bf16) / 19 (fp16) significant bits; below fp16's normal range (|c| < 2^-14) what hi keeps: 2^-25
+    bits = 16 if dtype == torch.bfloat16 else 19
+    err = (ops.resid_join(hi, lo) - c).abs() - c.abs() * 2.0 ** -bits
+    assert float(err.max()) <= (0.0 if dtype == torch.bfloat16 else 2.0 ** -25), float(err.max())
     cr = c.view(M, N // 64, 64)
     assert rel_l2(st[..., 0], cr.sum(-1)) < 1e-5 and rel_l2(st[..., 1], (cr * cr).sum(-1)) < 1e-5
     if tile == 0:
@@ -598,8 +598,7 @@ def test_96_row_direct_b_tile_is_a_bit_identical_alternative(dev):
     b2 = _rand((1024,), torch.float32, dev, 6)
     wf2 = ops.pack_b_frag(w2)
     h0 = _rand((M12, 1024), torch.float32, dev, 7, 2.0)
-    hi0 = h0.to(dt)
-    lo0 = (h0 - hi0.float()).to(dt)
+    hi0, lo0 = ops.resid_split(h0, dt)
     hi_a, lo_a = hi0.clone(), lo0.clone()
     st_a = ops.gemm_resid_split(a2, None, b2, hi_a, lo_a, w_frag=wf2)                      # product dispatch: 128-row tiles
     a3 = _rand((5 * 577, 1024), dt, dev, 8)
@@ -675,16 +674,15 @@ def test_gemm_row_map_scatter(dev, dtype, M, N, K, tile):
 
 
 def test_gather_rows_split(dev):
-    """slime_gather_rows_split: the tower's final feature_select / cast from the 2 x 16-bit split residual stream."""
-    from slime_amd import _lib
+    """slime_gather_rows_split: the tower's final feature_select / cast from the split residual stream (T + one signed byte, ABI 7)."""
+    from slime_amd import _lib, ops
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     n, S, D = 3, 577, 1024
     for dt, code in ((torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
         h = _rand((n * S, D), torch.float32, dev, 21, 3.0)
-        hi = h.to(dt)
-        lo = (h - hi.float()).to(dt)
-        want = (hi.float() + lo.float()).view(n, S, D)
+        hi, lo = ops.resid_split(h, dt)
+        want = ops.resid_join(hi, lo).view(n, S, D)
         for odt, ocode in ((torch.float32, _lib.F32), (torch.bfloat16, _lib.BF16), (torch.float16, _lib.F16)):
             for off, rows in ((1, S - 1), (0, S)):
                 out = torch.empty((n, rows, D), dtype=odt, device=dev)

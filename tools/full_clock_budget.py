@@ -50,7 +50,7 @@ def consumer(N, epi, zero):
 def producer(K, zero):
     a, wf, bias = operands(D, K, zero)
     h = torch.zeros(M, D) if zero else torch.randn(M, D)
-    hi = h.to(dt).to(dev); lo = (h.to(dev) - hi.float()).to(dt)
+    hi, lo = ops.resid_split(h.to(dev), dt)                      # the split residual stream: T + one signed byte (ABI 7)
     return lambda: ops.gemm_resid_split(a, None, bias, hi, lo, w_frag=wf)
 
 
