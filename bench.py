@@ -107,8 +107,8 @@ def gemm_algorithmic_bytes(kid, M, N, K, split_residual=True):
     b = M * K * 2 + N * K * 2 + N * 4                       # A, W (16 bit), bias
     if kid in (1, 5):                                       # q/k/v, fc1: LayerNorm-fold consumer, T output
         return b + M * N * 2 + M * (K // 64) * 8 + N * 4    # + output, row partial sums, colsum
-    if split_residual:                                      # out_proj / fc2 on the 2 x 16-bit split residual stream (round 5): hi + lo read and written
-        return b + 4 * M * N * 2 + M * (N // 64) * 8
+    if split_residual:                                      # out_proj / fc2 on the split residual stream: hi (T) + lo8 (one byte, ABI 7) read and written
+        return b + 2 * M * N * (2 + 1) + M * (N // 64) * 8
     return b + 2 * M * N * 4 + M * N * 2 + M * (N // 64) * 8   # rounds 1-4: fp32 residual read + write, T(h), partial sums
 
 
