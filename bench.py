@@ -803,6 +803,8 @@ def main():
                        "crops_per_gpu": per_rank, "images_per_step": IMAGES * (1 if strong else world), "grid": f"1+{LOCAL}",
                        "parallelism": f"crop-parallel dp{world}" + (" + all-gather of tower features" if world > 1 else ""),
                        "tower_streams": halves,
+                       # the tower's residual stream between the layers: T(h), which is the next GEMM's operand, + one signed byte per element (ABI 7)
+                       "residual_stream": {"layout": "hi = T(h) [16 bit] + lo8 [int8]", "bytes_per_element_per_update": 6, "abi": 7},
                        # resident packed weights (each tensor once): since ABI 5 a weight lives in HBM as its fragment-order image only
                        "packed_weight_MB": {"tower": round(ops.packed_weight_bytes(tower.vision_tower.packed(-2, 0)) / 1e6, 1),
                                             "adapter": round(ops.packed_weight_bytes(pg.mlp, pg.attn, post) / 1e6, 1),
